@@ -1,0 +1,736 @@
+// pyz_api.hip -- extern "C" entry points declared in include/pyz.h.
+// Host-side orchestration only: shape checks, workspace, kernel launches.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "pyz_common.h"
+#include "pyz_gemm.h"
+#include "pyz_kernels.h"
+#include "pyz_rng.h"
+
+namespace {
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+int ensure_bytes(void **ptr, size_t *cap, size_t need, pyz_mlp *m) {
+  if (*cap >= need) return PYZ_OK;
+  if (*ptr) PYZ_HIP(hipFree(*ptr));
+  *ptr = nullptr;
+  *cap = 0;
+  PYZ_HIP(hipMalloc(ptr, need));
+  m->ws_bytes += need;
+  *cap = need;
+  return PYZ_OK;
+}
+
+struct Extra {  // lazily sized buffers kept beside the plan
+  size_t grad_cap = 0, grad2_cap = 0, qsave_cap = 0, part_cap = 0, part2_cap = 0, scal_cap = 0;
+  double *part2 = nullptr;
+  size_t tab_cap_bytes = 0;
+  void *tab_host = nullptr;  // pinned
+  size_t tab_host_cap = 0;
+};
+
+}  // namespace
+
+// The opaque handle = plan + lazily grown buffers.
+struct pyz_mlp_full : pyz_mlp {
+  Extra x;
+};
+
+namespace {
+
+inline pyz_mlp_full *full(pyz_mlp *m) { return static_cast<pyz_mlp_full *>(m); }
+
+int need_grad(pyz_mlp *m, int P) {
+  return ensure_bytes((void **)&m->grad, &full(m)->x.grad_cap, sizeof(float) * (size_t)P * m->D + 64, m);
+}
+int need_grad2(pyz_mlp *m, int P) {
+  return ensure_bytes((void **)&m->grad2, &full(m)->x.grad2_cap, sizeof(float) * (size_t)P * m->D + 64, m);
+}
+int need_qsave(pyz_mlp *m, int P) {
+  return ensure_bytes((void **)&m->qsave, &full(m)->x.qsave_cap, sizeof(float) * (size_t)P * m->D + 64, m);
+}
+int need_part(pyz_mlp *m, size_t n_doubles) {
+  return ensure_bytes((void **)&m->part, &full(m)->x.part_cap, sizeof(double) * n_doubles, m);
+}
+int need_part2(pyz_mlp *m, size_t n_doubles) {
+  return ensure_bytes((void **)&full(m)->x.part2, &full(m)->x.part2_cap, sizeof(double) * n_doubles, m);
+}
+
+int check_call(const pyz_mlp *m, int P, int batch) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (batch <= 0 || batch > m->max_batch)
+    return pyz_fail(PYZ_E_SHAPE, "batch %d outside [1, %d] of the plan", batch, m->max_batch);
+  if (P <= 0 || P > m->max_p)
+    return pyz_fail(PYZ_E_SHAPE, "particle count %d outside [1, %d] of the plan", P, m->max_p);
+  return PYZ_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// forward over all layers; activations land in m->act[l]
+void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
+                    const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st) {
+  for (int l = 0; l < m->L; ++l) {
+    DenseArgs g{};
+    g.K = m->dims[l];
+    g.N = m->dims[l + 1];
+    if (l == 0) {
+      g.in = x;
+      g.in_pstride = 0;
+      g.row_idx = row_idx;
+    } else {
+      g.in = m->act[l - 1];
+      g.in_pstride = (long long)m->max_batch * g.K;
+      g.row_idx = nullptr;
+    }
+    g.lda = g.K;
+    g.theta = theta;
+    g.theta_pstride = theta_ps;
+    g.w_off = m->w_off[l];
+    g.out = m->act[l];
+    g.out_pstride = (long long)m->max_batch * g.N;
+    g.act = m->acts[l];
+    g.vec = (g.K % 8 == 0) && aligned16(g.in) ? 1 : 0;
+    g.ctl = ctl;
+    pyz_launch_fwd(g, grid_batch, P, st);
+  }
+}
+
+void launch_loss(pyz_mlp *m, int P, const void *y, const int32_t *row_idx, int grid_batch, const StepCtl *ctl,
+                 bool want_delta, hipStream_t st) {
+  LossArgs g{};
+  const int C = m->dims[m->L];
+  g.out_last = m->act[m->L - 1];
+  g.pstride = (long long)m->max_batch * C;
+  g.C = C;
+  g.y = y;
+  g.delta = want_delta ? m->delta[m->L - 1] : nullptr;
+  g.part = m->part;
+  g.nblk = cdiv(m->max_batch, 256);
+  g.act_last = m->acts[m->L - 1];
+  g.ctl = ctl;
+  g.row_idx = row_idx;
+  dim3 grid(cdiv(grid_batch, 256), P);
+  // partial slots of blocks past grid_batch must read as zero: the finalisers sum nblk of them
+  if ((int)grid.x < g.nblk) g.nblk = grid.x;
+  if (m->loss == PYZ_LOSS_SCCE)
+    hipLaunchKernelGGL(k_loss_scce, grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(k_loss_mse, grid, dim3(256), 0, st, g);
+}
+
+inline int loss_nblk(const pyz_mlp *m, int grid_batch) { return std::min(cdiv(m->max_batch, 256), cdiv(grid_batch, 256)); }
+
+void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
+                     const int32_t *row_idx, int grid_batch, const StepCtl *ctl, float *grad, hipStream_t st) {
+  for (int l = m->L - 1; l >= 0; --l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    if (l > 0) {  // delta[l-1] = (delta[l] W_l^T) * act'(h_{l-1})
+      DenseArgs g{};
+      g.K = K;
+      g.N = N;
+      g.in = m->delta[l];
+      g.in_pstride = (long long)m->max_batch * N;
+      g.lda = N;
+      g.theta = theta;
+      g.theta_pstride = theta_ps;
+      g.w_off = m->w_off[l];
+      g.out = m->delta[l - 1];
+      g.out_pstride = (long long)m->max_batch * K;
+      g.aux = m->act[l - 1];
+      g.aux_pstride = (long long)m->max_batch * K;
+      g.act = m->acts[l - 1];
+      g.vec = (N % 8 == 0) && (m->w_off[l] % 4 == 0) && (P == 1 || theta_ps % 4 == 0) && aligned16(theta) ? 1 : 0;
+      g.ctl = ctl;
+      pyz_launch_bwd_data(g, grid_batch, P, st);
+    }
+    DenseArgs g{};
+    g.K = K;
+    g.N = N;
+    if (l == 0) {
+      g.in = x;
+      g.in_pstride = 0;
+      g.row_idx = row_idx;
+    } else {
+      g.in = m->act[l - 1];
+      g.in_pstride = (long long)m->max_batch * K;
+    }
+    g.lda = K;
+    g.aux = m->delta[l];
+    g.aux_pstride = (long long)m->max_batch * N;
+    g.out = grad;
+    g.out_pstride = m->D;
+    g.w_off = m->w_off[l];
+    g.ctl = ctl;
+    pyz_launch_bwd_weight(g, grid_batch, P, st);
+  }
+}
+
+int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
+            int slot0 = 0) {
+  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+int check_loss_combo(const pyz_mlp *m) {
+  const int last = m->acts[m->L - 1];
+  if (m->loss == PYZ_LOSS_SCCE && last != PYZ_ACT_SOFTMAX)
+    return pyz_fail(PYZ_E_INVALID, "SparseCategoricalCrossentropy needs a softmax last layer");
+  if (m->loss == PYZ_LOSS_MSE && last == PYZ_ACT_SOFTMAX)
+    return pyz_fail(PYZ_E_INVALID, "MeanSquaredError on a softmax last layer is not supported");
+  return PYZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pyz_version(void) { return PYZ_VERSION; }
+
+const char *pyz_last_error(void) { return pyz_err_slot().c_str(); }
+
+int pyz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, int loss, int max_batch,
+                   int max_particles, pyz_mlp **out) {
+  if (!out || !h_dims || !h_acts) return pyz_fail(PYZ_E_INVALID, "null argument");
+  *out = nullptr;
+  if (n_layers < 1 || n_layers > PYZ_MAX_LAYERS) return pyz_fail(PYZ_E_INVALID, "n_layers %d outside [1, %d]", n_layers, PYZ_MAX_LAYERS);
+  if (max_batch < 1 || max_particles < 1) return pyz_fail(PYZ_E_INVALID, "max_batch and max_particles must be >= 1");
+  if (max_particles > 65535) return pyz_fail(PYZ_E_INVALID, "max_particles %d > 65535", max_particles);
+  if (loss != PYZ_LOSS_SCCE && loss != PYZ_LOSS_MSE) return pyz_fail(PYZ_E_INVALID, "unknown loss %d", loss);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return pyz_fail(PYZ_E_NODEV, "no HIP device visible");
+  pyz_mlp_full *m = new pyz_mlp_full();
+  m->L = n_layers;
+  m->loss = loss;
+  m->max_batch = max_batch;
+  m->max_p = max_particles;
+  long long off = 0;
+  for (int l = 0; l <= n_layers; ++l) {
+    if (h_dims[l] < 1) {
+      delete m;
+      return pyz_fail(PYZ_E_INVALID, "dims[%d] = %d", l, h_dims[l]);
+    }
+    m->dims[l] = h_dims[l];
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const int a = h_acts[l];
+    if (a < PYZ_ACT_LINEAR || a > PYZ_ACT_SOFTMAX || (a == PYZ_ACT_SOFTMAX && l != n_layers - 1)) {
+      delete m;
+      return pyz_fail(PYZ_E_INVALID, "activation %d at layer %d is not supported", a, l);
+    }
+    m->acts[l] = a;
+    m->w_off[l] = off;
+    off += (long long)(m->dims[l] + 1) * m->dims[l + 1];
+  }
+  m->D = off;
+  auto fail = [&](int rc) {
+    pyz_mlp_destroy(m);
+    return rc;
+  };
+  for (int l = 0; l < n_layers; ++l) {
+    const size_t bytes = sizeof(float) * (size_t)max_particles * max_batch * m->dims[l + 1] + 64;
+    if (hipMalloc((void **)&m->act[l], bytes) != hipSuccess || hipMalloc((void **)&m->delta[l], bytes) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
+    m->ws_bytes += 2 * bytes;
+  }
+  if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
+  if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
+  const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
+  if (hipMalloc((void **)&m->scal, scal) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "scalar allocation failed"));
+  m->ws_bytes += scal;
+  {
+    const int rc = need_part(m, (size_t)max_particles * cdiv(max_batch, 256) + 8);
+    if (rc != PYZ_OK) return fail(rc);
+  }
+  *out = m;
+  return PYZ_OK;
+}
+
+int pyz_mlp_destroy(pyz_mlp *mm) {
+  if (!mm) return PYZ_OK;
+  pyz_mlp_full *m = full(mm);
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  for (int l = 0; l < PYZ_MAX_LAYERS; ++l) {
+    if (m->act[l]) (void)hipFree(m->act[l]);
+    if (m->delta[l]) (void)hipFree(m->delta[l]);
+  }
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (m->x.tab_host) (void)hipHostFree(m->x.tab_host);
+  if (m->h_pinned) (void)hipHostFree(m->h_pinned);
+  delete m;
+  return PYZ_OK;
+}
+
+int64_t pyz_mlp_param_count(const pyz_mlp *m) { return m ? m->D : -1; }
+int64_t pyz_mlp_workspace_bytes(const pyz_mlp *m) { return m ? (int64_t)m->ws_bytes : -1; }
+
+// ---------------------------------------------------------------- G1
+int pyz_mlp_forward(pyz_mlp *m, const float *d_theta, int P, const float *d_x, const int32_t *d_row_idx, int batch,
+                    float *d_out, void *stream) {
+  int rc = check_call(m, P, batch);
+  if (rc) return rc;
+  if (!d_theta || !d_x || !d_out) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  launch_forward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, st);
+  const int C = m->dims[m->L];
+  hipLaunchKernelGGL(k_forward_finish, dim3(cdiv(batch, 256), P), dim3(256), 0, st, m->act[m->L - 1],
+                     (long long)m->max_batch * C, C, m->acts[m->L - 1] == PYZ_ACT_SOFTMAX ? 1 : 0, batch, d_out);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- G1-G3
+int pyz_mlp_loss_grad(pyz_mlp *m, const float *d_theta, int P, const float *d_x, const void *d_y,
+                      const int32_t *d_row_idx, int batch, float *d_grad, float *d_loss, void *stream) {
+  int rc = check_call(m, P, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_theta || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  launch_forward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, st);
+  launch_loss(m, P, d_y, d_row_idx, batch, m->ctl, d_grad != nullptr, st);
+  if (d_grad) launch_backward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, d_grad, st);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, loss_nblk(m, batch), m->ctl, d_loss);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- S1
+int pyz_sgd_step(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, const int32_t *d_row_idx, int batch,
+                 float lr, float *d_loss, void *stream) {
+  int rc = check_call(m, 1, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_theta || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if ((rc = need_grad(m, 1))) return rc;
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, lr, 0, 0, 0, st))) return rc;
+  launch_forward(m, d_theta, m->D, 1, d_x, d_row_idx, batch, m->ctl, st);
+  launch_loss(m, 1, d_y, d_row_idx, batch, m->ctl, true, st);
+  launch_backward(m, d_theta, m->D, 1, d_x, d_row_idx, batch, m->ctl, m->grad, st);
+  hipLaunchKernelGGL(k_sgd_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, m->grad, m->D, m->ctl, m->part,
+                     loss_nblk(m, batch), d_loss);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- L2/L3
+static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
+                             const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
+                             uint64_t seed, const float *unit_noise, float *loss, hipStream_t st) {
+  const StepCtl *ctl = m->ctl + slot;
+  launch_forward(m, theta, m->D, 1, x, row_idx, grid_batch, ctl, st);
+  launch_loss(m, 1, y, row_idx, grid_batch, ctl, true, st);
+  launch_backward(m, theta, m->D, 1, x, row_idx, grid_batch, ctl, m->grad, st);
+  SgldArgs a{};
+  a.theta = theta;
+  a.mean = mean;
+  a.sq_mean = sq;
+  a.grad = m->grad;
+  a.D = m->D;
+  a.ctl = ctl;
+  a.next = chained ? m->ctl + (slot ^ 1) : nullptr;
+  a.tab_bs = m->tab_bs;
+  a.tab_lr = m->tab_lr;
+  a.row_stride = row_stride;
+  a.seed = seed;
+  a.unit_noise = unit_noise;
+  a.part = m->part;
+  a.nblk = loss_nblk(m, grid_batch);
+  a.loss = loss;
+  a.loss_indexed = chained ? 1 : 0;
+  hipLaunchKernelGGL(k_sgld_update, dim3(cdiv(cdiv(m->D, 4), 256)), dim3(256), 0, st, a);
+}
+
+int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
+                  const int32_t *d_row_idx, int batch, float lr, int64_t n, uint64_t seed, const float *d_unit_noise,
+                  float *d_loss, void *stream) {
+  int rc = check_call(m, 1, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_theta || !d_mean || !d_sq_mean || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
+  if ((rc = need_grad(m, 1))) return rc;
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, lr, n, 0, 0, st))) return rc;
+  launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, batch, 0, false, 0, seed, d_unit_noise, d_loss, st);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
+                 const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
+                 int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  int rc = check_loss_combo(m);
+  if (rc) return rc;
+  if (n_steps <= 0) return pyz_fail(PYZ_E_INVALID, "n_steps must be positive");
+  if (slot0 < 0 || slot0 + n_steps > 0x7fffffff) return pyz_fail(PYZ_E_INVALID, "slot0 out of range");
+  if (!d_theta || !d_mean || !d_sq_mean || !d_x || !d_y || !d_row_idx || !h_batch_sizes || !h_lr || !d_losses)
+    return pyz_fail(PYZ_E_INVALID, "null pointer");
+  int bmax = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    if (h_batch_sizes[s] <= 0 || h_batch_sizes[s] > m->max_batch)
+      return pyz_fail(PYZ_E_SHAPE, "batch size %d of step %d outside [1, %d]", h_batch_sizes[s], s, m->max_batch);
+    bmax = std::max(bmax, h_batch_sizes[s]);
+  }
+  if ((rc = need_grad(m, 1))) return rc;
+  pyz_mlp_full *f = full(m);
+  hipStream_t st = as_stream(stream);
+  // per-run tables (one padding entry: the last step prepares a slot nobody reads)
+  const size_t n_tab = (size_t)n_steps + 1;
+  if (m->tab_cap < (int)n_tab) {
+    const size_t cap = std::max<size_t>(n_tab, 65536);  // generous: the table pointers are baked into the graph
+    if (m->tab_bs) PYZ_HIP(hipFree(m->tab_bs));
+    if (m->tab_lr) PYZ_HIP(hipFree(m->tab_lr));
+    m->tab_bs = nullptr;
+    m->tab_lr = nullptr;
+    PYZ_HIP(hipMalloc((void **)&m->tab_bs, sizeof(int32_t) * cap));
+    PYZ_HIP(hipMalloc((void **)&m->tab_lr, sizeof(float) * cap));
+    m->tab_cap = (int)cap;
+    // table pointers are baked into a captured graph
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+  }
+  if (f->x.tab_host_cap < 8 * n_tab) {
+    if (f->x.tab_host) PYZ_HIP(hipHostFree(f->x.tab_host));
+    f->x.tab_host = nullptr;
+    PYZ_HIP(hipHostMalloc(&f->x.tab_host, 8 * n_tab));
+    f->x.tab_host_cap = 8 * n_tab;
+  }
+  // the previous run's copies must have left the pinned buffer before it is rewritten
+  PYZ_HIP(hipStreamSynchronize(st));
+  int32_t *hb = reinterpret_cast<int32_t *>(f->x.tab_host);
+  float *hl = reinterpret_cast<float *>(hb + n_tab);
+  std::memcpy(hb, h_batch_sizes, sizeof(int32_t) * n_steps);
+  std::memcpy(hl, h_lr, sizeof(float) * n_steps);
+  hb[n_steps] = h_batch_sizes[n_steps - 1];
+  hl[n_steps] = h_lr[n_steps - 1];
+  PYZ_HIP(hipMemcpyAsync(m->tab_bs, hb, sizeof(int32_t) * n_tab, hipMemcpyHostToDevice, st));
+  PYZ_HIP(hipMemcpyAsync(m->tab_lr, hl, sizeof(float) * n_tab, hipMemcpyHostToDevice, st));
+  const long long row_stride = m->max_batch;
+  if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0))) return rc;
+
+  int s = 0;
+  const int G = 8;  // steps per captured graph (even: the StepCtl ping-pong returns to slot 0)
+  if (use_graph && st != nullptr && n_steps >= G) {
+    // everything baked into the graph goes into the key
+    unsigned long long key = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+    mix((unsigned long long)(uintptr_t)d_theta); mix((unsigned long long)(uintptr_t)d_mean);
+    mix((unsigned long long)(uintptr_t)d_sq_mean); mix((unsigned long long)(uintptr_t)d_x);
+    mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
+    mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
+    mix((unsigned long long)(uintptr_t)m->tab_bs);
+    if (!m->graph_exec || m->graph_key != key) {
+      if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+      if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+      PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      for (int k = 0; k < G; ++k)
+        launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
+                         nullptr, d_losses, st);
+      hipGraph_t gr = nullptr;
+      PYZ_HIP(hipStreamEndCapture(st, &gr));
+      m->graph = gr;
+      PYZ_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+      m->graph_key = key;
+    }
+    for (; s + G <= n_steps; s += G) PYZ_HIP(hipGraphLaunch(m->graph_exec, st));
+  }
+  for (; s < n_steps; ++s)
+    launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
+                     d_losses, st);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- B2-B4
+int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float *d_x, const void *d_y,
+                 const int32_t *d_row_idx, int batch, float lr, float alpha, float prior_mean, float prior_rho,
+                 int64_t step, uint64_t seed, const float *d_eps, float *d_cost, void *stream) {
+  int rc = check_call(m, 1, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_mu || !d_rho || !d_w || !d_x || !d_y || !d_cost) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if ((rc = need_grad(m, 1))) return rc;
+  const int nblk_kl = cdiv(cdiv(m->D, 4), 256);
+  if ((rc = need_part2(m, nblk_kl))) return rc;
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, lr, step, 0, 0, st))) return rc;
+  BbbArgs a{};
+  a.mu = d_mu;
+  a.rho = d_rho;
+  a.w = d_w;
+  a.grad = m->grad;
+  a.D = m->D;
+  a.lr = lr;
+  a.alpha = alpha;
+  a.prior_mean = prior_mean;
+  a.prior_rho = prior_rho;
+  a.seed = seed;
+  a.step = (uint32_t)step;
+  a.eps = d_eps;
+  a.part_kl = full(m)->x.part2;
+  a.nblk_kl = nblk_kl;
+  a.part_loss = m->part;
+  a.nblk_loss = loss_nblk(m, batch);
+  a.ctl = m->ctl;
+  a.cost = d_cost;
+  hipLaunchKernelGGL(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
+  launch_forward(m, d_w, m->D, 1, d_x, d_row_idx, batch, m->ctl, st);
+  launch_loss(m, 1, d_y, d_row_idx, batch, m->ctl, true, st);
+  launch_backward(m, d_w, m->D, 1, d_x, d_row_idx, batch, m->ctl, m->grad, st);
+  hipLaunchKernelGGL(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- H2-H5
+int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_y, int n_rows, int L, float epsilon,
+                 float mass, float prior_mean, float prior_sigma, int burning, const float *h_uniform, int64_t step,
+                 uint64_t seed, const float *d_unit_p, float *d_stats, void *stream) {
+  int rc = check_call(m, P, n_rows);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_q || !d_x || !d_y || !d_stats || !h_uniform) return pyz_fail(PYZ_E_INVALID, "null pointer");
+  if (L < 0) return pyz_fail(PYZ_E_INVALID, "L must be >= 0");
+  if ((rc = need_grad(m, P)) || (rc = need_grad2(m, P)) || (rc = need_qsave(m, P))) return rc;
+  const int nblk4 = cdiv(cdiv(m->D, 4), 256), nblk1 = cdiv(m->D, 256);
+  if ((rc = need_part2(m, (size_t)P * 2 * nblk1 + 8))) return rc;
+  hipStream_t st = as_stream(stream);
+  pyz_mlp_full *f = full(m);
+  float *loss = m->scal;               // [P]
+  float *energies = m->scal + m->max_p;  // [P*8]
+  float *unif = m->scal + 9 * m->max_p;  // [P]
+  PYZ_HIP(hipMemcpyAsync(unif, h_uniform, sizeof(float) * P, hipMemcpyHostToDevice, st));
+  if ((rc = set_ctl(m, 0, n_rows, 0.0f, step, 0, 0, st))) return rc;
+  HmcArgs a{};
+  a.q = d_q;
+  a.p = m->grad2;
+  a.qsave = m->qsave;
+  a.grad = m->grad;
+  a.D = m->D;
+  a.m = mass;
+  a.prior_mean = prior_mean;
+  a.prior_sigma = prior_sigma;
+  a.n_train = (float)n_rows;
+  a.seed = seed;
+  a.step = (uint32_t)step;
+  a.unit_p = d_unit_p;
+  a.part = f->x.part2;
+  auto grad_eval = [&]() {
+    launch_forward(m, d_q, m->D, P, d_x, nullptr, n_rows, m->ctl, st);
+    launch_loss(m, P, d_y, nullptr, n_rows, m->ctl, true, st);
+    launch_backward(m, d_q, m->D, P, d_x, nullptr, n_rows, m->ctl, m->grad, st);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, loss_nblk(m, n_rows), m->ctl, loss);
+  };
+  // momentum, snapshot, K0 and the prior part of U0
+  a.nblk = nblk4;
+  hipLaunchKernelGGL(k_hmc_begin, dim3(nblk4, P), dim3(256), 0, st, a);
+  grad_eval();
+  hipLaunchKernelGGL(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk4, loss, a.n_train, mass, energies, 0);
+  // half kick + first drift (HMC.py:82-84); with L == 0 the two half kicks share the gradient
+  a.nblk = nblk1;
+  if (L == 0) {
+    a.kick1 = epsilon / 2;
+    a.kick2 = epsilon / 2;
+    a.drift = 0.0f;
+    hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+  } else {
+    a.kick1 = epsilon / 2;
+    a.kick2 = 0.0f;
+    a.drift = epsilon / mass;
+    hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+    for (int i = 1; i <= L; ++i) {
+      grad_eval();
+      a.kick1 = epsilon;
+      if (i < L) {
+        a.kick2 = 0.0f;
+        a.drift = epsilon / mass;
+      } else {  // last full kick and the closing half kick use the same gradient (HMC.py:86-87)
+        a.kick2 = epsilon / 2;
+        a.drift = 0.0f;
+      }
+      hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+    }
+  }
+  // K1, U1 (the loss of the last gradient evaluation is the loss at the proposal)
+  hipLaunchKernelGGL(k_hmc_end_energy, dim3(nblk1, P), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk1, loss, a.n_train, mass, energies, 1);
+  hipLaunchKernelGGL(k_hmc_accept, dim3(cdiv(P, 64)), dim3(64), 0, st, energies, unif, burning, d_stats, P);
+  hipLaunchKernelGGL(k_hmc_restore, dim3(nblk1, P), dim3(256), 0, st, d_q, m->qsave, d_stats, m->D);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- V2-V4
+int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                  float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y, const int32_t *d_row_idx,
+                  int batch, float lr, float gamma, int64_t t, int sweep, float *d_loss, void *stream) {
+  int rc = check_call(m, n_local, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_particles || !d_all || !d_adam_m || !d_adam_v || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n_total < n_local || row0 < 0 || row0 + n_local > n_total) return pyz_fail(PYZ_E_INVALID, "rows [%d, %d) outside the %d particles", row0, row0 + n_local, n_total);
+  if (t < 1) return pyz_fail(PYZ_E_INVALID, "Adam step t must be >= 1");
+  if (!(gamma > 0.0f)) return pyz_fail(PYZ_E_INVALID, "gamma must be positive");
+  if (sweep != PYZ_SWEEP_GAUSS_SEIDEL && sweep != PYZ_SWEEP_JACOBI) return pyz_fail(PYZ_E_INVALID, "unknown sweep %d", sweep);
+  if (sweep == PYZ_SWEEP_GAUSS_SEIDEL && (d_all != d_particles || n_local != n_total))
+    return pyz_fail(PYZ_E_INVALID, "the Gauss-Seidel sweep needs the whole particle matrix on this device");
+  if (n_total > 1024) return pyz_fail(PYZ_E_INVALID, "more than 1024 particles");
+  if ((rc = need_grad(m, n_local))) return rc;
+  const int nblk = std::max(1, std::min(256, cdiv(m->D, 512)));
+  const int rows_at_once = sweep == PYZ_SWEEP_JACOBI ? n_local : 1;
+  if ((rc = need_part2(m, (size_t)rows_at_once * nblk * n_total + 8))) return rc;
+  hipStream_t st = as_stream(stream);
+  float *loss = m->scal;  // [n_local]
+  if ((rc = set_ctl(m, 0, batch, lr, t, 0, 0, st))) return rc;
+  // all loss gradients in one particle-batched pass: g_i depends on particle i only (SVGD.py:104-111)
+  launch_forward(m, d_particles, m->D, n_local, d_x, d_row_idx, batch, m->ctl, st);
+  launch_loss(m, n_local, d_y, d_row_idx, batch, m->ctl, true, st);
+  launch_backward(m, d_particles, m->D, n_local, d_x, d_row_idx, batch, m->ctl, m->grad, st);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, loss_nblk(m, batch), m->ctl, loss);
+  SvgdArgs a{};
+  a.particles = d_particles;
+  a.all = d_all;
+  a.all_rw = nullptr;
+  a.adam_m = d_adam_m;
+  a.adam_v = d_adam_v;
+  a.grad = m->grad;
+  a.D = m->D;
+  a.M = n_total;
+  a.n_local = n_local;
+  a.row0 = row0;
+  const double b1t = std::pow(0.9, (double)t), b2t = std::pow(0.999, (double)t);
+  a.lr_t = (float)((double)lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
+  a.gamma = gamma;
+  a.part = full(m)->x.part2;
+  a.nblk = nblk;
+  const size_t lds = sizeof(double) * (size_t)(n_total + 16);
+  if (sweep == PYZ_SWEEP_JACOBI) {
+    a.i_local = -1;
+    hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, n_local), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
+  } else {
+    for (int i = 0; i < n_local; ++i) {
+      a.i_local = i;
+      hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, 1), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
+    }
+  }
+  hipLaunchKernelGGL(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- R1
+int pyz_predict(pyz_mlp *m, const float *d_weights, int n_samples, const float *d_x, int n, float *d_samples,
+                float *d_mean, void *stream) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (n_samples <= 0 || n <= 0) return pyz_fail(PYZ_E_INVALID, "n_samples and n must be positive");
+  if (n > m->max_batch) return pyz_fail(PYZ_E_SHAPE, "n %d exceeds the plan's max_batch %d", n, m->max_batch);
+  if (!d_weights || !d_x || !d_mean) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  hipStream_t st = as_stream(stream);
+  int rc = set_ctl(m, 0, n, 0.0f, 0, 0, 0, st);
+  if (rc) return rc;
+  const int C = m->dims[m->L];
+  const int softmax = m->acts[m->L - 1] == PYZ_ACT_SOFTMAX ? 1 : 0;
+  for (int s0 = 0; s0 < n_samples; s0 += m->max_p) {
+    const int S = std::min(m->max_p, n_samples - s0);
+    launch_forward(m, d_weights + (long long)s0 * m->D, m->D, S, d_x, nullptr, n, m->ctl, st);
+    hipLaunchKernelGGL(k_predict_finish, dim3(cdiv(n, 256)), dim3(256), 0, st, m->act[m->L - 1],
+                       (long long)m->max_batch * C, C, softmax, S, n,
+                       d_samples ? d_samples + (long long)s0 * n * C : nullptr, d_mean, s0 > 0 ? 1 : 0,
+                       1.0f / (float)n_samples);
+  }
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- noise
+int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step, float mean, float std,
+                    void *stream) {
+  if (!d_out || n <= 0) return pyz_fail(PYZ_E_INVALID, "bad output buffer");
+  hipLaunchKernelGGL(k_fill_normal, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, as_stream(stream), d_out, (long long)n,
+                     seed, stream_id, step, mean, std);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- measurement hook
+int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta, int P, const float *d_x,
+                           const int32_t *d_row_idx, int batch, float *d_grad, int iters, void *stream) {
+  int rc = check_call(m, P, batch);
+  if (rc) return rc;
+  if (layer < 0 || layer >= m->L || kind < 0 || kind > 2 || iters < 1) return pyz_fail(PYZ_E_INVALID, "bad kind/layer/iters");
+  if (kind == 1 && layer == 0) return pyz_fail(PYZ_E_INVALID, "layer 0 has no data gradient");
+  if (!d_theta || !d_x || (kind == 2 && !d_grad)) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  const int K = m->dims[layer], N = m->dims[layer + 1];
+  DenseArgs g{};
+  g.K = K;
+  g.N = N;
+  g.theta = d_theta;
+  g.theta_pstride = m->D;
+  g.w_off = m->w_off[layer];
+  g.ctl = m->ctl;
+  if (kind == 1) {
+    g.in = m->delta[layer];
+    g.in_pstride = (long long)m->max_batch * N;
+    g.lda = N;
+    g.out = m->delta[layer - 1];
+    g.out_pstride = (long long)m->max_batch * K;
+    g.aux = m->act[layer - 1];
+    g.aux_pstride = (long long)m->max_batch * K;
+    g.act = m->acts[layer - 1];
+    g.vec = (N % 8 == 0) && (m->w_off[layer] % 4 == 0) && (P == 1 || m->D % 4 == 0) && aligned16(d_theta) ? 1 : 0;
+  } else {
+    if (layer == 0) {
+      g.in = d_x;
+      g.in_pstride = 0;
+      g.row_idx = d_row_idx;
+    } else {
+      g.in = m->act[layer - 1];
+      g.in_pstride = (long long)m->max_batch * K;
+    }
+    g.lda = K;
+    if (kind == 0) {
+      g.out = m->act[layer];
+      g.out_pstride = (long long)m->max_batch * N;
+      g.act = m->acts[layer];
+      g.vec = (K % 8 == 0) && aligned16(g.in) ? 1 : 0;
+    } else {
+      g.aux = m->delta[layer];
+      g.aux_pstride = (long long)m->max_batch * N;
+      g.out = d_grad;
+      g.out_pstride = m->D;
+    }
+  }
+  for (int i = 0; i < iters; ++i) {
+    if (kind == 0) pyz_launch_fwd(g, batch, P, st);
+    else if (kind == 1) pyz_launch_bwd_data(g, batch, P, st);
+    else pyz_launch_bwd_weight(g, batch, P, st);
+  }
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// pyz_common.h -- shared host/device definitions of the gfx950 backend.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pyz.h"
+
+#define PYZ_MAX_LAYERS 16
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Per-step scalars.  They live in device memory so that a captured hipGraph of
+// one step can be replayed for every step: the last kernel of a step advances
+// the block from the per-run tables (k_advance_ctl).
+struct StepCtl {
+  int32_t batch;       // rows in this step's batch (ragged last batch allowed)
+  float lr;            // learning rate of this step
+  long long n;         // optimizer step count (moment divisor / RNG step)
+  long long row_off;   // offset of this step's rows inside the row-index table
+  int32_t i;           // index of the step inside the current run
+  int32_t slot0;       // first loss / row-table slot of the current run
+};
+
+// ---------------------------------------------------------------- host errors
+inline std::string &pyz_err_slot() {
+  static thread_local std::string s;
+  return s;
+}
+
+inline int pyz_fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  pyz_err_slot() = buf;
+  return code;
+}
+
+#define PYZ_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return pyz_fail(e_ == hipErrorOutOfMemory ? PYZ_E_OOM : PYZ_E_HIP, "%s failed: %s (%s:%d)", \
+                      #call, hipGetErrorString(e_), __FILE__, __LINE__);                     \
+  } while (0)
+
+#define PYZ_LAUNCH_CHECK()                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess)                                                                     \
+      return pyz_fail(PYZ_E_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),   \
+                      __FILE__, __LINE__);                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------- the plan
+struct pyz_mlp {
+  int L = 0;
+  int dims[PYZ_MAX_LAYERS + 1] = {0};
+  int acts[PYZ_MAX_LAYERS] = {0};
+  long long w_off[PYZ_MAX_LAYERS] = {0};  // offset of layer l's kernel (bias follows) in the flat vector
+  int loss = 0;
+  int max_batch = 0, max_p = 0;
+  long long D = 0;
+  size_t ws_bytes = 0;
+  // device workspace (library-owned)
+  float *act[PYZ_MAX_LAYERS] = {nullptr};    // output of layer l: (P, max_batch, dims[l+1])
+  float *delta[PYZ_MAX_LAYERS] = {nullptr};  // d loss / d pre-activation of layer l, same shape
+  float *grad = nullptr;                     // (P, D)
+  float *grad2 = nullptr;                    // (P, D) second scratch (HMC momentum, SVGD phi)
+  float *qsave = nullptr;                    // (P, D) HMC snapshot
+  double *part = nullptr;                    // reduction partials
+  int part_len = 0;
+  float *scal = nullptr;                     // small device scalars
+  StepCtl *ctl = nullptr;                    // device StepCtl
+  int32_t *tab_bs = nullptr;                 // per-run tables (device)
+  float *tab_lr = nullptr;
+  int tab_cap = 0;
+  float *h_pinned = nullptr;                 // pinned host staging
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  unsigned long long graph_key = 0;
+};

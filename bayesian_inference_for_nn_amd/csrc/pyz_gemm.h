@@ -1,0 +1,271 @@
+// pyz_gemm.h -- exact-fp32 MFMA kernels for the Dense layers of the hot path.
+//
+// Replaces Keras Dense forward (called at Pyesian/optimizers/SGLD.py:55,
+// SGD.py:57, HMC.py:155, BBB.py:144, SVGD.py:106) and the Dense part of
+// tf.GradientTape.gradient (SGLD.py:64, HMC.py:134, BBB.py:173, SVGD.py:110).
+//
+// Design (gfx950): every GEMM of this path is small (<= 1024 x 785 x 400), so
+// the kernels are shaped for occupancy and launch count, not for a big tile:
+//   * one wave computes one 32x32 output tile over a slice of the reduction
+//     dimension with v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bit-exact
+//     fmaf chain, 64 cycles per SIMD, one accumulator chain reaches full rate);
+//   * a workgroup is S in {1,2,4,8,16} waves that split the reduction of the
+//     SAME tile and combine through LDS in a fixed order (deterministic, no
+//     atomics, no partial slabs in HBM); S is picked at launch so that
+//     tiles x S covers the 256 CUs x 4 SIMDs;
+//   * operand fragments are loaded straight from L2/HBM in the layout the MFMA
+//     wants: a float4 per lane along a contiguous reduction axis feeds four
+//     MFMAs (reduction order permuted identically for A and B), or one dword
+//     per lane when the tile axis is the contiguous one (128-B coalesced rows);
+//   * the bias is row K of the augmented (K+1) x N matrix [W; b], which is
+//     exactly the flat layout (kernel then bias), so forward adds it with one
+//     extra MFMA step and the weight-gradient kernel writes [dW; db] in place;
+//   * blockIdx.y is the particle / chain / sample index: (P, D) parameter
+//     matrices are processed in one launch.
+#pragma once
+
+#include "pyz_common.h"
+
+struct DenseArgs {
+  const float *in;            // A-side activations (forward/weight-grad: layer input; data-grad: delta)
+  long long in_pstride;       // particle stride of `in` (0 when shared, e.g. the data batch)
+  int lda;                    // row stride of `in`
+  const float *theta;         // (P, D) flat parameters
+  long long theta_pstride;
+  long long w_off;            // offset of this layer's kernel in the flat vector
+  int K, N;                   // layer input / output width
+  float *out;                 // destination (see each kernel)
+  long long out_pstride;
+  const float *aux;           // data-grad: previous layer's output (for act'); weight-grad: delta
+  long long aux_pstride;
+  int act;                    // forward: this layer's activation; data-grad: previous layer's
+  int vec;                    // float4 loads legal along the reduction axis
+  const StepCtl *ctl;         // batch (rows) and row-index offset of this step
+  const int32_t *row_idx;     // optional gather of `in` rows (layer 0 only)
+};
+
+__device__ __forceinline__ f32x16 pyz_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float pyz_act(float z, int act) {
+  switch (act) {
+    case PYZ_ACT_RELU: return z < 0.0f ? 0.0f : z;  // NaN propagates, like tf.nn.relu
+    case PYZ_ACT_TANH: return tanhf(z);
+    case PYZ_ACT_SIGMOID: return 1.0f / (1.0f + expf(-z));
+    default: return z;  // linear; softmax is applied by the loss / predict kernels on the logits
+  }
+}
+
+// d act / d z through the activation OUTPUT h
+__device__ __forceinline__ float pyz_act_grad(float h, int act) {
+  switch (act) {
+    case PYZ_ACT_RELU: return h > 0.0f ? 1.0f : 0.0f;
+    case PYZ_ACT_TANH: return 1.0f - h * h;
+    case PYZ_ACT_SIGMOID: return h * (1.0f - h);
+    default: return 1.0f;
+  }
+}
+
+// Combine the S partial 32x32 tiles of a workgroup through LDS (fixed order)
+// and hand each element to `store(row_in_tile, col_in_tile, value)`.
+// C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <class F>
+__device__ __forceinline__ void pyz_tile_epilogue(const f32x16 &acc, float *red, F store) {
+  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = l & 31, h = l >> 5;
+  if (S == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) store((i & 3) + 8 * (i >> 2) + 4 * h, r, acc[i]);
+    return;
+  }
+  float *my = red + w * 1024;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) my[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    float s = red[e];
+    for (int ww = 1; ww < S; ++ww) s += red[ww * 1024 + e];
+    store(e >> 5, e & 31, s);
+  }
+}
+
+// ---------------------------------------------------------------- forward
+// out[p][m][n] = act( sum_k in[row(m)][k] * W[k][n] + b[n] ),  m < batch, n < N.
+__global__ void k_dense_fwd(DenseArgs g) {
+  extern __shared__ float red[];
+  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = l & 31, h = l >> 5;
+  const int batch = g.ctl->batch;
+  const int tiles_n = (g.N + 31) >> 5;
+  const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  if (m0 >= batch) return;  // uniform per workgroup
+  const int p = blockIdx.y;
+  const int K = g.K, N = g.N;
+  const int m = min(m0 + r, batch - 1), n = min(n0 + r, N - 1);  // clamped: rows/cols past the edge are never stored
+  long long row = m;
+  if (g.row_idx) row = g.row_idx[g.ctl->row_off + m];
+  const float *ap = g.in + p * g.in_pstride + row * g.lda;
+  const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
+  f32x16 acc = {0};
+  const int c8 = g.vec ? (K >> 3) : 0;
+  {
+    const int cb = (c8 * w) / S, ce = (c8 * (w + 1)) / S;
+#pragma unroll 2
+    for (int c = cb; c < ce; ++c) {
+      const int k = 8 * c + 4 * h;
+      const float4 a4 = *reinterpret_cast<const float4 *>(ap + k);
+      const float *bp = wp + (long long)k * N;
+      const float b0 = bp[0], b1 = bp[N], b2 = bp[2 * (long long)N], b3 = bp[3 * (long long)N];
+      acc = pyz_mfma(a4.x, b0, acc);
+      acc = pyz_mfma(a4.y, b1, acc);
+      acc = pyz_mfma(a4.z, b2, acc);
+      acc = pyz_mfma(a4.w, b3, acc);
+    }
+  }
+  {
+    const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
+    const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
+    for (int s = sb; s < se; ++s) {
+      const int kk = t0 + 2 * s + h;
+      const bool vk = kk < K;
+      const int kc = vk ? kk : 0;
+      const float a = vk ? ap[kc] : 0.0f;
+      const float b = vk ? wp[(long long)kc * N] : 0.0f;
+      acc = pyz_mfma(a, b, acc);
+    }
+  }
+  if (w == 0) {  // bias: row K of [W; b] against a column of ones
+    const float a = h == 0 ? 1.0f : 0.0f;
+    const float b = h == 0 ? wp[(long long)K * N] : 0.0f;
+    acc = pyz_mfma(a, b, acc);
+  }
+  float *op = g.out + p * g.out_pstride;
+  const int act = g.act;
+  pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
+    const int mm = m0 + ro, nn = n0 + co;
+    if (mm < batch && nn < N) op[(long long)mm * N + nn] = pyz_act(v, act);
+  });
+}
+
+// ---------------------------------------------------------------- data gradient
+// out[p][m][j] = ( sum_n delta[p][m][n] * W[j][n] ) * act'(hprev[p][m][j]),  j < K.
+// `in` = delta (row stride N), `aux` = previous layer's output (row stride K).
+__global__ void k_dense_bwd_data(DenseArgs g) {
+  extern __shared__ float red[];
+  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = l & 31, h = l >> 5;
+  const int batch = g.ctl->batch;
+  const int K = g.K, N = g.N;
+  const int tiles_j = (K + 31) >> 5;
+  const int m0 = (blockIdx.x / tiles_j) * 32, j0 = (blockIdx.x % tiles_j) * 32;
+  if (m0 >= batch) return;
+  const int p = blockIdx.y;
+  const int m = min(m0 + r, batch - 1), j = min(j0 + r, K - 1);
+  const float *ap = g.in + p * g.in_pstride + (long long)m * N;
+  const float *wp = g.theta + p * g.theta_pstride + g.w_off + (long long)j * N;
+  f32x16 acc = {0};
+  const int c8 = g.vec ? (N >> 3) : 0;
+  {
+    const int cb = (c8 * w) / S, ce = (c8 * (w + 1)) / S;
+#pragma unroll 2
+    for (int c = cb; c < ce; ++c) {
+      const int k = 8 * c + 4 * h;
+      const float4 a4 = *reinterpret_cast<const float4 *>(ap + k);
+      const float4 b4 = *reinterpret_cast<const float4 *>(wp + k);
+      acc = pyz_mfma(a4.x, b4.x, acc);
+      acc = pyz_mfma(a4.y, b4.y, acc);
+      acc = pyz_mfma(a4.z, b4.z, acc);
+      acc = pyz_mfma(a4.w, b4.w, acc);
+    }
+  }
+  {
+    const int t0 = 8 * c8, steps = (N - t0 + 1) >> 1;
+    const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
+    for (int s = sb; s < se; ++s) {
+      const int kk = t0 + 2 * s + h;
+      const bool vk = kk < N;
+      const int kc = vk ? kk : 0;
+      const float a = vk ? ap[kc] : 0.0f;
+      const float b = vk ? wp[kc] : 0.0f;
+      acc = pyz_mfma(a, b, acc);
+    }
+  }
+  float *op = g.out + p * g.out_pstride;
+  const float *hp = g.aux + p * g.aux_pstride;
+  const int act = g.act;
+  pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
+    const int mm = m0 + ro, jj = j0 + co;
+    if (mm < batch && jj < K) {
+      const long long o = (long long)mm * K + jj;
+      op[o] = v * pyz_act_grad(hp[o], act);
+    }
+  });
+}
+
+// ---------------------------------------------------------------- weight gradient
+// out[p][w_off + i*N + n] = sum_b A(b, i) * delta[p][b][n],  i <= K, n < N, with
+// A(b, i) = in[row(b)][i] for i < K and 1 for i == K (the bias row).
+// `in` = layer input, `aux` = delta (row stride N).
+__global__ void k_dense_bwd_weight(DenseArgs g) {
+  extern __shared__ float red[];
+  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int r = l & 31, h = l >> 5;
+  const int batch = g.ctl->batch;
+  const int K = g.K, N = g.N;
+  const int tiles_n = (N + 31) >> 5;
+  const int i0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int p = blockIdx.y;
+  const int i = i0 + r, n = min(n0 + r, N - 1);
+  const int ic = min(i, K - 1);
+  const bool is_w = i < K, is_b = i == K;
+  const float *ap = g.in + p * g.in_pstride + ic;
+  const float *dp = g.aux + p * g.aux_pstride + n;
+  const int32_t *idx = g.row_idx ? g.row_idx + g.ctl->row_off : nullptr;
+  f32x16 acc = {0};
+  const int steps = (batch + 1) >> 1;
+  const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
+#pragma unroll 4
+  for (int s = sb; s < se; ++s) {
+    const int b = 2 * s + h;
+    const bool vb = b < batch;
+    const int bc = vb ? b : 0;
+    const long long row = idx ? (long long)idx[bc] : (long long)bc;
+    float a = ap[row * g.lda];
+    a = is_w ? a : (is_b ? 1.0f : 0.0f);
+    a = vb ? a : 0.0f;
+    const float d = vb ? dp[(long long)bc * N] : 0.0f;
+    acc = pyz_mfma(a, d, acc);
+  }
+  float *op = g.out + p * g.out_pstride + g.w_off;
+  pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
+    const int ii = i0 + ro, nn = n0 + co;
+    if (ii <= K && nn < N) op[(long long)ii * N + nn] = v;
+  });
+}
+
+// ---------------------------------------------------------------- launch helpers
+static inline int pyz_pick_waves(long long tiles, long long mfma_steps) {
+  int S = 1;
+  while (S < 16 && tiles * S < 1536 && mfma_steps / (2 * S) >= 6) S *= 2;
+  return S;
+}
+
+static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
+  const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.N + 31) / 32);
+  const int S = pyz_pick_waves(tiles * P, (g.K + 1) / 2 + 1);
+  hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+}
+
+static inline void pyz_launch_bwd_data(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
+  const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.K + 31) / 32);
+  const int S = pyz_pick_waves(tiles * P, (g.N + 1) / 2);
+  hipLaunchKernelGGL(k_dense_bwd_data, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+}
+
+static inline void pyz_launch_bwd_weight(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
+  const long long tiles = (long long)((g.K + 1 + 31) / 32) * ((g.N + 31) / 32);
+  const int S = pyz_pick_waves(tiles * P, (grid_batch + 1) / 2);
+  hipLaunchKernelGGL(k_dense_bwd_weight, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+}

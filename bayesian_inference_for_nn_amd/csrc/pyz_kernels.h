@@ -1,0 +1,574 @@
+// pyz_kernels.h -- loss, update and reduction kernels of the optimizer steps.
+// Each kernel cites the reference lines whose arithmetic it carries out.
+#pragma once
+
+#include "pyz_common.h"
+#include "pyz_gemm.h"
+#include "pyz_rng.h"
+
+#define PYZ_LOG_SQRT_2PI 0.918938533204672741780329736406f
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ double pyz_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the workgroup; result valid in thread 0.  `sm` holds >= 16 doubles.
+__device__ __forceinline__ double pyz_block_sum(double v, double *sm) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  v = pyz_wave_sum(v);
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) s += sm[i];
+  return s;
+}
+
+// sum `n` partials (fixed order) -- called by ONE thread
+__device__ __forceinline__ double pyz_sum_partials(const double *part, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += part[i];
+  return s;
+}
+
+__device__ __forceinline__ float pyz_softplus(float x) {
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float pyz_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------- step control
+__global__ void k_set_ctl(StepCtl *ctl, int batch, float lr, long long n, long long row_off, int i, int slot0) {
+  ctl->batch = batch;
+  ctl->lr = lr;
+  ctl->n = n;
+  ctl->row_off = row_off;
+  ctl->i = i;
+  ctl->slot0 = slot0;
+}
+
+// The last kernel of a step prepares the OTHER StepCtl slot for the next step
+// (ping-pong: nobody reads that slot during this step).
+__device__ __forceinline__ void pyz_prepare_next(const StepCtl *ctl, StepCtl *next, const int32_t *tab_bs,
+                                                 const float *tab_lr, long long row_stride) {
+  const int i2 = ctl->i + 1;
+  next->i = i2;
+  next->batch = tab_bs[i2];
+  next->lr = tab_lr[i2];
+  next->n = ctl->n + 1;
+  next->row_off = ctl->row_off + row_stride;
+  next->slot0 = ctl->slot0;
+}
+
+// ---------------------------------------------------------------- losses
+struct LossArgs {
+  const float *out_last;   // (P, max_batch, C): logits (softmax last layer) or outputs
+  long long pstride;
+  int C;
+  const void *y;           // int32 labels (SCCE) / float targets (MSE), indexed like the data rows
+  float *delta;            // (P, max_batch, C) or nullptr (loss only)
+  double *part;            // (P, nblk) partial sums of the per-row loss
+  int nblk;
+  int act_last;
+  const StepCtl *ctl;
+  const int32_t *row_idx;
+};
+
+// SparseCategoricalCrossentropy on a softmax last layer, reduction 'auto' = mean
+// over the batch (Dataset.py:152-159; used at SGLD.py:57, HMC.py:157, BBB.py:122,
+// SVGD.py:107): loss_m = logsumexp(z_m) - z_m[y_m]; delta = (softmax - onehot)/B.
+__global__ void k_loss_scce(LossArgs g) {
+  __shared__ double sm[16];
+  const int batch = g.ctl->batch, C = g.C, p = blockIdx.y;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  double lm = 0.0;
+  if (m < batch) {
+    const float *z = g.out_last + p * g.pstride + (long long)m * C;
+    const long long row = g.row_idx ? (long long)g.row_idx[g.ctl->row_off + m] : (long long)m;
+    const int y = reinterpret_cast<const int32_t *>(g.y)[row];
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.0f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float lse = mx + logf(se);
+    const float zy = (y >= 0 && y < C) ? z[y] : __builtin_nanf("");
+    lm = (double)(lse - zy);
+    if (g.delta) {
+      float *d = g.delta + p * g.pstride + (long long)m * C;
+      const float inv = 1.0f / (float)batch;
+      for (int c = 0; c < C; ++c) d[c] = (expf(z[c] - lse) - (c == y ? 1.0f : 0.0f)) * inv;
+    }
+  }
+  const double s = pyz_block_sum(lm, sm);
+  if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = s;
+}
+
+// MeanSquaredError: mean over the last axis, then over the batch;
+// delta = 2 (yhat - y) / (B * C) * act'(yhat).
+__global__ void k_loss_mse(LossArgs g) {
+  __shared__ double sm[16];
+  const int batch = g.ctl->batch, C = g.C, p = blockIdx.y;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  double lm = 0.0;
+  if (m < batch) {
+    const float *o = g.out_last + p * g.pstride + (long long)m * C;
+    const long long row = g.row_idx ? (long long)g.row_idx[g.ctl->row_off + m] : (long long)m;
+    const float *y = reinterpret_cast<const float *>(g.y) + row * C;
+    float acc = 0.0f;
+    const float sc = 2.0f / ((float)batch * (float)C);
+    float *d = g.delta ? g.delta + p * g.pstride + (long long)m * C : nullptr;
+    for (int c = 0; c < C; ++c) {
+      const float e = o[c] - y[c];
+      acc += e * e;
+      if (d) d[c] = sc * e * pyz_act_grad(o[c], g.act_last);
+    }
+    lm = (double)(acc / (float)C);
+  }
+  const double s = pyz_block_sum(lm, sm);
+  if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = s;
+}
+
+// loss[p] = (sum of the row-loss partials) / batch
+__global__ void k_loss_finalize(const double *part, int nblk, const StepCtl *ctl, float *loss) {
+  const int p = blockIdx.x;
+  if (threadIdx.x == 0) loss[p] = (float)(pyz_sum_partials(part + p * nblk, nblk) / (double)ctl->batch);
+}
+
+// ---------------------------------------------------------------- SGD / SGLD
+// SGD.step update (SGD.py:66-69): theta -= lr * grad.
+__global__ void k_sgd_update(float *theta, const float *grad, long long D, const StepCtl *ctl, const double *part,
+                             int nblk, float *loss) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float lr = ctl->lr;
+  if (e < D) theta[e] = theta[e] - lr * grad[e];
+  if (e == 0) loss[0] = (float)(pyz_sum_partials(part, nblk) / (double)ctl->batch);
+}
+
+// SGLD.step (SGLD.py:64-93), fused over the flat vector:
+//   noise = lr * z;  theta += -lr * (grad + noise)
+//   mean <- (mean * n + theta) / (n + 1);  sq_mean <- (sq_mean * n + theta^2) / (n + 1)
+// Each thread owns four consecutive elements (one Philox call).
+struct SgldArgs {
+  float *theta, *mean, *sq_mean;
+  const float *grad;
+  long long D;
+  const StepCtl *ctl;
+  StepCtl *next;            // may be nullptr (eager)
+  const int32_t *tab_bs;
+  const float *tab_lr;
+  long long row_stride;
+  uint64_t seed;
+  const float *unit_noise;  // optional injected N(0,1)
+  const double *part;
+  int nblk;
+  float *loss;              // eager: slot 0; run: indexed by ctl->i
+  int loss_indexed;
+};
+
+__global__ void k_sgld_update(SgldArgs g) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  const float lr = g.ctl->lr;
+  const long long n = g.ctl->n;
+  if (e0 < g.D) {
+    float z[4];
+    if (g.unit_noise) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = (e0 + j < g.D) ? g.unit_noise[e0 + j] : 0.0f;
+    } else {
+      const float4 q = pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)n, (uint64_t)t);
+      z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+    }
+    const float fn = (float)n, fn1 = fn + 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = e0 + j;
+      if (e < g.D) {
+        const float noise = lr * z[j];
+        const float th = g.theta[e] + (-lr) * (g.grad[e] + noise);
+        g.theta[e] = th;
+        g.mean[e] = (g.mean[e] * fn + th) / fn1;
+        g.sq_mean[e] = (g.sq_mean[e] * fn + th * th) / fn1;
+      }
+    }
+  }
+  if (t == 0) {
+    float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
+    lo[0] = (float)(pyz_sum_partials(g.part, g.nblk) / (double)g.ctl->batch);
+    if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
+  }
+}
+
+// ---------------------------------------------------------------- BBB
+struct BbbArgs {
+  float *mu, *rho, *w;
+  const float *grad;
+  long long D;
+  float lr, alpha, prior_mean, prior_rho;
+  uint64_t seed;
+  uint32_t step;
+  const float *eps;      // optional injected N(0,1)
+  double *part_kl;       // (nblk_kl)
+  int nblk_kl;
+  const double *part_loss;
+  int nblk_loss;
+  const StepCtl *ctl;
+  float *cost;           // [0] = cost, [1] = data loss, [2] = log q - log p
+};
+
+__device__ __forceinline__ void pyz_bbb_eps(const BbbArgs &g, long long t, float *z) {
+  const long long e0 = 4 * t;
+  if (g.eps) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = (e0 + j < g.D) ? g.eps[e0 + j] : 0.0f;
+  } else {
+    const float4 q = pyz_normal4(g.seed, PYZ_STREAM_BBB, g.step, (uint64_t)t);
+    z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+  }
+}
+
+// BBB._update_weights (BBB.py:218-246): w = mu + softplus(rho) * eps, and the two
+// Gaussian log-likelihood sums of _cost_function (BBB.py:51-124):
+//   sum log N(w; mu, softplus rho) - sum log N(w; mu_p, softplus rho_p).
+__global__ void k_bbb_sample(BbbArgs g) {
+  __shared__ double sm[16];
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  double kl = 0.0;
+  if (e0 < g.D) {
+    float z[4];
+    pyz_bbb_eps(g, t, z);
+    const float sp = pyz_softplus(g.prior_rho), lsp = logf(sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = e0 + j;
+      if (e < g.D) {
+        const float mu = g.mu[e], sg = pyz_softplus(g.rho[e]);
+        const float w = z[j] * sg + mu;
+        g.w[e] = w;
+        const float a = (w - mu) / sg, b = (w - g.prior_mean) / sp;
+        const float lq = -0.5f * a * a - logf(sg) - PYZ_LOG_SQRT_2PI;
+        const float lp = -0.5f * b * b - lsp - PYZ_LOG_SQRT_2PI;
+        kl += (double)lq - (double)lp;
+      }
+    }
+  }
+  const double s = pyz_block_sum(kl, sm);
+  if (threadIdx.x == 0) g.part_kl[blockIdx.x] = s;
+}
+
+// BBB.step gradients and update (BBB.py:152-201), closed forms of the three
+// tape.gradient calls (derivation cross-checked in tests/test_oracle_kat.py):
+//   d mu  = alpha (w - mu) / sigma^2
+//   d rho = alpha (-1/sigma + (w - mu)^2 / sigma^3) sigmoid(rho)
+//   d w   = d loss/d w + alpha (-(w - mu)/sigma^2 + (w - mu_p)/sigma_p^2)
+//   mu  <- mu  - lr (d mu + d w);   rho <- rho - lr (eps sigmoid(rho) d w + d rho)
+__global__ void k_bbb_update(BbbArgs g) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  if (e0 < g.D) {
+    float z[4];
+    pyz_bbb_eps(g, t, z);
+    const float sp = pyz_softplus(g.prior_rho), isp2 = 1.0f / (sp * sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = e0 + j;
+      if (e < g.D) {
+        const float mu = g.mu[e], rho = g.rho[e], w = g.w[e];
+        const float sg = pyz_softplus(rho), sig = pyz_sigmoid(rho);
+        const float d = w - mu, is2 = 1.0f / (sg * sg);
+        const float g_mu = g.alpha * d * is2;
+        const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
+        const float g_w = g.grad[e] + g.alpha * (-d * is2 + (w - g.prior_mean) * isp2);
+        g.mu[e] = mu - g.lr * (g_mu + g_w);
+        g.rho[e] = rho - g.lr * (z[j] * sig * g_w + g_rho);
+      }
+    }
+  }
+  if (t == 0) {
+    const float loss = (float)(pyz_sum_partials(g.part_loss, g.nblk_loss) / (double)g.ctl->batch);
+    const float kl = (float)pyz_sum_partials(g.part_kl, g.nblk_kl);
+    g.cost[0] = loss + g.alpha * kl;
+    g.cost[1] = loss;
+    g.cost[2] = kl;
+  }
+}
+
+// ---------------------------------------------------------------- HMC
+struct HmcArgs {
+  float *q;              // (P, D)
+  float *p;              // (P, D) momentum
+  float *qsave;          // (P, D)
+  const float *grad;     // (P, D) d loss / d q (mean loss)
+  long long D;
+  float m, prior_mean, prior_sigma, n_train;
+  float kick1, kick2;    // p -= kick1 * dU; p -= kick2 * dU  (kick2 = 0 when unused)
+  float drift;           // q += drift * p   (0 when unused)
+  uint64_t seed;
+  uint32_t step;
+  const float *unit_p;   // optional injected N(0,1), (P, D)
+  double *part;          // (P, 2, nblk): [0] = sum log N(q), [1] = sum p^2
+  int nblk;
+};
+
+// _sample_kinetic_energy (HMC.py:168-171): p = m * z;  snapshot q (HMC.py:81);
+// partial sums for K0 (HMC.py:161-166) and the prior part of U0 (HMC.py:150-154).
+__global__ void k_hmc_begin(HmcArgs g) {
+  __shared__ double sm[16];
+  const int c = blockIdx.y;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  double sp2 = 0.0, slp = 0.0;
+  if (e0 < g.D) {
+    float z[4];
+    if (g.unit_p) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = (e0 + j < g.D) ? g.unit_p[c * g.D + e0 + j] : 0.0f;
+    } else {
+      const float4 v = pyz_normal4(g.seed, PYZ_STREAM_HMC + 16u * (uint32_t)c, g.step, (uint64_t)t);
+      z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
+    }
+    const float ls = logf(g.prior_sigma);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = e0 + j;
+      if (e < g.D) {
+        const float q = g.q[c * g.D + e];
+        const float pm = g.m * z[j];
+        g.p[c * g.D + e] = pm;
+        g.qsave[c * g.D + e] = q;
+        sp2 += (double)(pm * pm);
+        const float a = (q - g.prior_mean) / g.prior_sigma;
+        slp += (double)(-0.5f * a * a - ls - PYZ_LOG_SQRT_2PI);
+      }
+    }
+  }
+  const double s0 = pyz_block_sum(slp, sm);
+  const double s1 = pyz_block_sum(sp2, sm);
+  if (threadIdx.x == 0) {
+    g.part[(c * 2 + 0) * g.nblk + blockIdx.x] = s0;
+    g.part[(c * 2 + 1) * g.nblk + blockIdx.x] = s1;
+  }
+}
+
+// _step_p (HMC.py:128-136) with dU/dq = (q - mu_p)/sigma_p^2 + N * dloss/dq, optionally
+// followed by _step_q (HMC.py:138-141) q += (eps/m) p.  Two sequential kicks keep the
+// reference's rounding when a full and a half kick share one gradient (HMC.py:86-87).
+__global__ void k_hmc_kick_drift(HmcArgs g) {
+  const int c = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.D) return;
+  const long long o = c * g.D + e;
+  const float q = g.q[o];
+  const float dU = (q - g.prior_mean) / (g.prior_sigma * g.prior_sigma) + g.n_train * g.grad[o];
+  float p = g.p[o];
+  p = p - g.kick1 * dU;
+  if (g.kick2 != 0.0f) p = p - g.kick2 * dU;
+  g.p[o] = p;
+  if (g.drift != 0.0f) g.q[o] = q + g.drift * p;
+}
+
+// partial sums for K1 and the prior part of U1 at the end of the trajectory
+__global__ void k_hmc_end_energy(HmcArgs g) {
+  __shared__ double sm[16];
+  const int c = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double sp2 = 0.0, slp = 0.0;
+  if (e < g.D) {
+    const float q = g.q[c * g.D + e], p = g.p[c * g.D + e];
+    sp2 = (double)(p * p);
+    const float a = (q - g.prior_mean) / g.prior_sigma;
+    slp = (double)(-0.5f * a * a - logf(g.prior_sigma) - PYZ_LOG_SQRT_2PI);
+  }
+  const double s0 = pyz_block_sum(slp, sm);
+  const double s1 = pyz_block_sum(sp2, sm);
+  if (threadIdx.x == 0) {
+    g.part[(c * 2 + 0) * g.nblk + blockIdx.x] = s0;
+    g.part[(c * 2 + 1) * g.nblk + blockIdx.x] = s1;
+  }
+}
+
+// energies[c*4 + {0,1}] = {U, K} from the partials and the mean loss (HMC.py:149-166)
+__global__ void k_hmc_energy_finalize(const double *part, int nblk, const float *loss, float n_train, float m,
+                                      float *energies, int slot) {
+  const int c = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const float slp = (float)pyz_sum_partials(part + (c * 2 + 0) * nblk, nblk);
+  const float sp2 = (float)pyz_sum_partials(part + (c * 2 + 1) * nblk, nblk);
+  float U = 0.0f - slp;              // potential_energy -= reduce_sum(log_prob)
+  U = U + loss[c] * n_train;         // += loss * cardinality
+  const float K = (1.0f / (2.0f * m)) * sp2;
+  energies[c * 8 + 2 * slot + 0] = U;
+  energies[c * 8 + 2 * slot + 1] = K;
+  energies[c * 8 + 4 + slot] = loss[c];
+}
+
+// Metropolis test (HMC.py:91): accept iff burning or u < exp(K0 + U0 - K1 - U1).
+// stats (P, 8) = {accepted, loss, U0, K0, U1, K1, log_ratio, 0}
+__global__ void k_hmc_accept(const float *energies, const float *uniform, int burning, float *stats, int P) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= P) return;
+  const float U0 = energies[c * 8 + 0], K0 = energies[c * 8 + 1], U1 = energies[c * 8 + 2], K1 = energies[c * 8 + 3];
+  const float lr = K0 + U0 - K1 - U1;
+  const bool acc = burning || (uniform[c] < expf(lr));
+  stats[c * 8 + 0] = acc ? 1.0f : 0.0f;
+  stats[c * 8 + 1] = acc ? energies[c * 8 + 5] : energies[c * 8 + 4];
+  stats[c * 8 + 2] = U0;
+  stats[c * 8 + 3] = K0;
+  stats[c * 8 + 4] = U1;
+  stats[c * 8 + 5] = K1;
+  stats[c * 8 + 6] = lr;
+  stats[c * 8 + 7] = 0.0f;
+}
+
+// rejected chains get their snapshot back (HMC.py:97-101)
+__global__ void k_hmc_restore(float *q, const float *qsave, const float *stats, long long D) {
+  const int c = blockIdx.y;
+  if (stats[c * 8] != 0.0f) return;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < D) q[c * D + e] = qsave[c * D + e];
+}
+
+// ---------------------------------------------------------------- SVGD
+struct SvgdArgs {
+  float *particles;       // (n_local, D) this rank's rows (updated)
+  const float *all;       // (M, D) matrix the kernel row is evaluated against
+  float *all_rw;          // == all when the sweep updates it in place (Gauss-Seidel, one GPU), else nullptr
+  float *adam_m, *adam_v; // (n_local, D)
+  const float *grad;      // (n_local, D) loss gradients
+  long long D;
+  int M, n_local, row0;
+  int i_local;            // row handled by this launch (Gauss-Seidel) ; -1 = all rows (Jacobi)
+  float lr_t;             // lr * sqrt(1 - b2^t) / (1 - b1^t)
+  float gamma;
+  double *part;           // (n_rows, nblk, M) partial squared distances
+  int nblk;
+};
+
+// partial squared distances  sum_d (x_i[d] - x_j[d])^2  of row i against every j, in
+// float64 (SVGD.py:198-201 evaluates them on the float64 particle matrix).
+// grid = (nblk, rows); each workgroup owns a D-chunk, each wave a subset of the j's;
+// lanes sweep the chunk and combine with wave shuffles only (no LDS, no barrier).
+__global__ void k_svgd_dist(SvgdArgs g) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int il = g.i_local >= 0 ? g.i_local : blockIdx.y;
+  const int i = g.row0 + il;
+  const long long chunk = (g.D + g.nblk - 1) / g.nblk;
+  const long long d0 = blockIdx.x * chunk, d1 = min(g.D, d0 + chunk);
+  const float *xi = g.all + (long long)i * g.D;
+  double *outp = g.part + ((long long)(g.i_local >= 0 ? 0 : blockIdx.y) * g.nblk + blockIdx.x) * g.M;
+  for (int j = w; j < g.M; j += nw) {
+    const float *xj = g.all + (long long)j * g.D;
+    double s = 0.0;
+    for (long long d = d0 + l; d < d1; d += 64) {
+      const double df = (double)xi[d] - (double)xj[d];
+      s += df * df;
+    }
+    s = pyz_wave_sum(s);
+    if (l == 0) outp[j] = s;
+  }
+}
+
+// phi_i = ( (sum_j K_ij) g_i + 2 gamma sum_j K_ij (x_i - x_j) ) / M   (SVGD.py:54-68)
+// followed by the particle's Keras legacy Adam step (SVGD.py:120, Appendix A3):
+//   m += (phi - m)(1 - b1); v += (phi^2 - v)(1 - b2); x -= lr_t m / (sqrt(v) + 1e-7)
+__global__ void k_svgd_update(SvgdArgs g) {
+  extern __shared__ double sd[];  // M doubles: K_ij
+  const int il = g.i_local >= 0 ? g.i_local : blockIdx.y;
+  const int i = g.row0 + il;
+  const double *pp = g.part + (long long)(g.i_local >= 0 ? 0 : blockIdx.y) * g.nblk * g.M;
+  for (int j = threadIdx.x; j < g.M; j += blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < g.nblk; ++b) s += pp[(long long)b * g.M + j];
+    sd[j] = exp(-(double)g.gamma * s);
+  }
+  __syncthreads();
+  float ksum = 0.0f;
+  for (int j = 0; j < g.M; ++j) ksum += (float)sd[j];
+  const long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= g.D) return;
+  const float xi = g.all[(long long)i * g.D + d];
+  double rep = 0.0;
+  for (int j = 0; j < g.M; ++j) rep += sd[j] * ((double)xi - (double)g.all[(long long)j * g.D + d]);
+  rep *= 2.0 * (double)g.gamma;
+  const long long o = (long long)il * g.D + d;
+  const float phi = (ksum * g.grad[o] + (float)rep) / (float)g.M;
+  float m = g.adam_m[o], v = g.adam_v[o];
+  m = m + (phi - m) * (1.0f - 0.9f);
+  v = v + (phi * phi - v) * (1.0f - 0.999f);
+  g.adam_m[o] = m;
+  g.adam_v[o] = v;
+  const float xn = g.particles[o] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+  g.particles[o] = xn;
+  if (g.all_rw && g.all_rw != g.particles) g.all_rw[(long long)i * g.D + d] = xn;
+}
+
+// d_loss[0] = sum_i loss_i / M   (SVGD.py:125)
+__global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < n_local; ++i) s += loss[i] / (float)M;
+    out[0] = s;
+  }
+}
+
+// ---------------------------------------------------------------- predict
+// BayesianModel.predict (BayesianModel.py:119-128): per-sample outputs with
+// NaN -> 0 and their mean.  last = (S, max_batch, C) logits or outputs.
+__global__ void k_predict_finish(const float *last, long long pstride, int C, int softmax, int S, int n,
+                                 float *samples, float *mean, int mean_accumulate, float inv_total) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  for (int c = 0; c < C; ++c) {
+    if (!mean_accumulate) mean[(long long)m * C + c] = 0.0f;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float *z = last + s * pstride + (long long)m * C;
+    float mx = 0.0f, lse = 0.0f;
+    if (softmax) {
+      mx = z[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+      float se = 0.0f;
+      for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+      lse = mx + logf(se);
+    }
+    for (int c = 0; c < C; ++c) {
+      float v = softmax ? expf(z[c] - lse) : z[c];
+      v = (v != v) ? 0.0f : v;
+      if (samples) samples[((long long)s * n + m) * C + c] = v;
+      mean[(long long)m * C + c] += v * inv_total;
+    }
+  }
+}
+
+// model output for pyz_mlp_forward: softmax (if any) applied, no NaN scrubbing
+__global__ void k_forward_finish(const float *last, long long pstride, int C, int softmax, int n, float *out) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (m >= n) return;
+  const float *z = last + s * pstride + (long long)m * C;
+  float lse = 0.0f;
+  if (softmax) {
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.0f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    lse = mx + logf(se);
+  }
+  for (int c = 0; c < C; ++c) out[((long long)s * n + m) * C + c] = softmax ? expf(z[c] - lse) : z[c];
+}
+
+// ---------------------------------------------------------------- noise
+__global__ void k_fill_normal(float *out, long long n, uint64_t seed, uint32_t stream, uint32_t step, float mean,
+                              float std) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  if (e0 >= n) return;
+  const float4 q = pyz_normal4(seed, stream, step, (uint64_t)t);
+  const float z[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e0 + j < n) out[e0 + j] = mean + std * z[j];
+}

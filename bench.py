@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SGLD grad-steps/s on the MLP 784->200->10, batch 1024
+(BASELINE.json configs[1]), one chain per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: forward, loss, backward, fused
+noise + parameter + moment update (Pyesian/optimizers/SGLD.py:46-95).  Inputs
+(data set, row-index plan, weights, moments) are resident in HBM before the timed
+region; the timed region is K steps bracketed by barrier + synchronize; the time
+is the max over ranks and `value` the whole-job steps/s.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (the layer-0 Dense GEMM: forward or weight
+                gradient, whichever is slower): algorithmic FLOP per launch /
+                its average duration from HIP events around back-to-back launches
+                on the bench stream, against the dense fp32 MFMA peak.
+  cpu_baseline  the oracle's eager torch-CPU restatement of the same step
+                (oracle/torch_eager.py, kind "port") on the host cores.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+DIMS = (784, 200, 10)
+BATCH = 1024
+N_ROWS = 48_000
+LR_UPPER, LR_LOWER, LR_GAMMA = 0.01, 0.003, 0.99      # reference tests/unittest2.py:73
+SEED = 2024
+FLOP_PER_STEP = 654.5e6        # C2 per grad-step
+BYTES_PER_STEP = 7.03e6
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Time the eager CPU restatement (reference op granularity) on a bounded sample."""
+    import torch
+    from oracle import mlp as o_mlp, torch_eager, sgld as o_sgld
+    from bayesian_inference_for_nn_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    spec = o_mlp.MLPSpec(DIMS, ("relu", "softmax"), "scce")
+    x, y = synth.mnist_like(8192)
+    xt, yt = torch.as_tensor(x), torch.as_tensor(y.astype(np.int64))
+    eager = torch_eager.EagerSGLD(spec, synth.glorot_uniform(DIMS), o_sgld.lr_schedule(10_000, LR_UPPER, LR_LOWER, LR_GAMMA),
+                                  generator=torch.Generator().manual_seed(0))
+    rng = np.random.default_rng(0)
+
+    def one():
+        idx = torch.as_tensor(rng.permutation(8192)[:BATCH])
+        eager.step(xt[idx], yt[idx])
+
+    for _ in range(5):
+        one()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s or n < 20:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} eager torch-CPU SGLD steps (fp32, batch {BATCH}, 784->200->10) in {dt:.1f} s; "
+                      "TensorFlow is not installed, so the reference's eager step is timed through oracle/torch_eager.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bayesian_inference_for_nn_amd import engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    spec = engine.MLPSpec(DIMS, ("relu", "softmax"), "scce")
+    D = spec.n_params
+    plan = engine.MLPPlan(spec, max_batch=BATCH)
+    x_h, y_h = synth.mnist_like(N_ROWS)
+    x = torch.as_tensor(x_h).to(dev)
+    y = torch.as_tensor(y_h).to(dev)
+    theta = torch.as_tensor(synth.glorot_uniform(DIMS)).to(dev)
+    mean = torch.zeros(D, device=dev)
+    sq_mean = torch.zeros(D, device=dev)
+    total = args.warmup + args.steps
+    idx_h, sizes = synth.batch_plan(N_ROWS, BATCH, total, seed=1236 + 1000 * rank)
+    idx = torch.as_tensor(idx_h).to(dev)
+    lrs = synth.sgld_lr_table(total, LR_UPPER, LR_LOWER, LR_GAMMA, 0, total)
+    losses = torch.zeros(total, device=dev)
+    stream = torch.cuda.Stream()
+    use_graph = not args.no_graph
+
+    def run(s0, n):
+        with torch.cuda.stream(stream):
+            plan.sgld_run(theta, mean, sq_mean, x, y, idx, sizes[s0:s0 + n], lrs[s0:s0 + n], s0, SEED + rank,
+                          losses, use_graph=use_graph, slot0=s0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(0, args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_loss = float(losses[total - 1].item())
+    if not np.isfinite(last_loss):
+        raise SystemExit(f"bench.py: non-finite loss {last_loss} on rank {rank}")
+
+    roof = None
+    if rank == 0:
+        # dominant kernel, timed alone with HIP events on the bench stream
+        iters = 300
+        row = idx[0].contiguous()
+        grad = torch.empty((1, D), device=dev)
+        yy = y
+        with torch.cuda.stream(stream):
+            plan.loss_grad(theta, x, yy, batch=BATCH, row_idx=row)      # fills the workspace (activations, deltas)
+            best = None
+            for kind, name in ((0, "k_dense_fwd[layer0]"), (2, "k_dense_bwd_weight[layer0]")):
+                plan.lib.pyz_bench_dense_kernel(plan.h, kind, 0, engine.ptr(theta), 1, engine.ptr(x), engine.ptr(row),
+                                                BATCH, engine.ptr(grad), 20, engine._stream())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                engine.check(plan.lib.pyz_bench_dense_kernel(plan.h, kind, 0, engine.ptr(theta), 1, engine.ptr(x),
+                                                             engine.ptr(row), BATCH, engine.ptr(grad), iters,
+                                                             engine._stream()))
+                e1.record(stream)
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / iters
+                if best is None or us > best[1]:
+                    best = (name, us)
+        flop = 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1]
+        achieved = flop / (best[1] * 1e-6) / 1e12
+        step_us = dt / args.steps * 1e6
+        roof = {"bound": "mfma", "kernel": best[0], "kernel_us": round(best[1], 3), "flop_per_launch": flop,
+                "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "whole_step": {"flop": FLOP_PER_STEP, "bytes": BYTES_PER_STEP, "us": round(step_us, 3),
+                               "tflops": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12, 3),
+                               "frac_mfma": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "gbps": round(BYTES_PER_STEP / (step_us * 1e-6) / 1e9, 1),
+                               "frac_hbm": round(BYTES_PER_STEP / (step_us * 1e-6) / 8.0e12, 5)}}
+
+    if rank == 0:
+        out = {
+            "metric": "posterior samples/sec (grad-steps/sec) on MLP 784->200->10, batch 1024",
+            "value": round(args.gpus * args.steps / dt, 2),
+            "unit": "grad-steps/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "SGLD, MLP 784->200->10 (D=159010), synthetic MNIST-shaped 48000x784 fp32 resident in HBM, "
+                                   "batch 1024 (last batch of an epoch 896), 1 chain per GPU, hipGraph replay"
+                                   if use_graph else "SGLD C2, eager launches",
+                       "lr": [LR_UPPER, LR_LOWER, LR_GAMMA], "seed": SEED, "final_loss": round(last_loss, 6),
+                       "parallelism": f"independent chains x{args.gpus} (replicas only, no data-path collective)"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/* pyz.h -- C-ABI of the MI355X (gfx950) backend for the Pyesian.optimizers hot path.
+ *
+ * The reference (leoelm/Bayesian_inference_for_NN, "Pyesian") has no FFI: the hot
+ * path sits behind the Python abstract class `Optimizer`
+ * (Pyesian/optimizers/Optimizer.py:14-165) whose subclasses run eager
+ * TensorFlow ops.  This header is the boundary a maintainer would bind with
+ * ctypes from inside those `step()` methods (INTEGRATION.md shows the stubs).
+ * Every entry point cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C linkage, plain pointers and sizes; no torch / HIP types.
+ *   - every function returns int: 0 = PYZ_OK, <0 = error; pyz_last_error()
+ *     returns the message of the calling thread's most recent failure.
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / torch-ROCm storage)
+ *     owned by the caller; h_* are host pointers.  `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).  Calls enqueue work and
+ *     return; scalar outputs live in device memory the caller reads after
+ *     synchronising its stream.
+ *   - a pyz_mlp handle owns its device workspace and is confined to one host
+ *     thread at a time.
+ *   - flat parameter order (HMC.py:177-183, SVGD.py:159-160,230-239,
+ *     nn/BayesianModel.py:73-77): for each Dense layer, kernel (in x out,
+ *     row-major) then bias (out).  "P" below is a particle/chain/sample count:
+ *     parameter matrices are (P, D) row-major.
+ *   - all arithmetic is float32 (the reference's dtype) unless stated.
+ */
+#ifndef PYZ_H
+#define PYZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYZ_VERSION 100 /* 0.1.0 */
+
+#define PYZ_OK 0
+#define PYZ_E_INVALID (-1) /* bad argument / unsupported combination */
+#define PYZ_E_SHAPE (-2)   /* batch / particle count exceeds the plan */
+#define PYZ_E_HIP (-3)     /* HIP runtime error (message has the HIP string) */
+#define PYZ_E_OOM (-4)     /* device allocation failed */
+#define PYZ_E_NODEV (-5)   /* no gfx950 device visible */
+
+/* activations of a Dense layer (Keras names) */
+#define PYZ_ACT_LINEAR 0
+#define PYZ_ACT_RELU 1
+#define PYZ_ACT_TANH 2
+#define PYZ_ACT_SIGMOID 3
+#define PYZ_ACT_SOFTMAX 4 /* last layer only */
+
+/* losses produced by Dataset.loss() (Pyesian/datasets/Dataset.py:152-159) */
+#define PYZ_LOSS_SCCE 0 /* SparseCategoricalCrossentropy on a softmax last layer; labels int32 (B) */
+#define PYZ_LOSS_MSE 1  /* MeanSquaredError; targets float32 (B, out) */
+
+/* SVGD sweep order */
+#define PYZ_SWEEP_GAUSS_SEIDEL 0 /* the reference: particle i sees updated rows 0..i-1 (SVGD.py:100-123) */
+#define PYZ_SWEEP_JACOBI 1       /* all rows from one snapshot (multi-GPU mode) */
+
+typedef struct pyz_mlp pyz_mlp;
+
+int pyz_version(void);
+const char *pyz_last_error(void);
+/* number of visible HIP devices (does not initialise a context beyond the count) */
+int pyz_device_count(void);
+
+/* ---- plan -------------------------------------------------------------------
+ * Dense stack parsed from the Keras JSON the reference passes to
+ * Optimizer.compile (Optimizer.py:43-62).  dims has n_layers+1 entries.
+ * max_batch bounds every batch (training, validation, prediction) and
+ * max_particles every P passed later; the workspace is sized for both. */
+int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, int loss,
+                   int max_batch, int max_particles, pyz_mlp **out);
+int pyz_mlp_destroy(pyz_mlp *mlp);
+int64_t pyz_mlp_param_count(const pyz_mlp *mlp);
+int64_t pyz_mlp_workspace_bytes(const pyz_mlp *mlp);
+
+/* ---- G1: Keras Dense forward (called at SGLD.py:55, SGD.py:57, HMC.py:155,
+ * BBB.py:144, SVGD.py:106; BayesianModel.py:124).  d_out is (P, batch, out):
+ * the model output (softmax applied when the last activation is softmax).
+ * d_row_idx (optional, int32[batch]) gathers rows of d_x: row m of the batch
+ * is d_x[d_row_idx[m]]. */
+int pyz_mlp_forward(pyz_mlp *mlp, const float *d_theta, int n_particles, const float *d_x,
+                    const int32_t *d_row_idx, int batch, float *d_out, void *stream);
+
+/* ---- G1-G3: forward + loss + tape.gradient (SGLD.py:54-64, HMC.py:128-136,
+ * BBB.py:140-173, SVGD.py:104-111).  d_loss is float32[P] (mean loss over the
+ * batch); d_grad is (P, D) or NULL (loss only: the validation passes of
+ * BBB.py:203-209 and SVGD.py:126-129). */
+int pyz_mlp_loss_grad(pyz_mlp *mlp, const float *d_theta, int n_particles, const float *d_x,
+                      const void *d_y, const int32_t *d_row_idx, int batch, float *d_grad,
+                      float *d_loss, void *stream);
+
+/* ---- S1: SGD.step update (SGD.py:56-69): theta <- theta - lr * grad. */
+int pyz_sgd_step(pyz_mlp *mlp, float *d_theta, const float *d_x, const void *d_y,
+                 const int32_t *d_row_idx, int batch, float lr, float *d_loss, void *stream);
+
+/* ---- L2/L3: SGLD.step (SGLD.py:54-95).  noise = lr * z, z ~ N(0,1) from the
+ * library's Philox stream (seed, step n) or from d_unit_noise (float32[D]) when
+ * given; theta += -lr * (grad + noise); mean/sq_mean running moments with
+ * count n.  d_loss receives the batch loss. */
+int pyz_sgld_step(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x,
+                  const void *d_y, const int32_t *d_row_idx, int batch, float lr, int64_t n,
+                  uint64_t seed, const float *d_unit_noise, float *d_loss, void *stream);
+
+/* Device-resident multi-step SGLD (the Optimizer.train loop, Optimizer.py:121-134,
+ * without per-step host work): step s in [0, n_steps) uses rows
+ * d_row_idx[(slot0+s)*max_batch .. +h_batch_sizes[s]) of the resident data set,
+ * learning rate h_lr[s] and count n0+s, and writes its batch loss to
+ * d_losses[slot0+s].  With use_graph != 0 (and a non-NULL stream) eight steps are
+ * captured once into a hipGraph and replayed; the per-step scalars live in device
+ * memory and are advanced by the last kernel of each step. */
+int pyz_sgld_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x,
+                 const void *d_y, const int32_t *d_row_idx, const int32_t *h_batch_sizes,
+                 const float *h_lr, int n_steps, int64_t n0, int64_t slot0, uint64_t seed,
+                 float *d_losses, int use_graph, void *stream);
+
+/* ---- B2-B4: BBB.step (BBB.py:128-201).  d_mu / d_rho are the variational
+ * parameters (D each); eps ~ N(0,1) from Philox (seed, step) or d_eps.
+ * Writes the sampled weights to d_w (D, used by the validation pass), the
+ * cost (loss + alpha * (log q - log p)) to d_cost[0] and the data loss to
+ * d_cost[1].  prior_rho is the raw rho: sigma_p = softplus(prior_rho). */
+int pyz_bbb_step(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const float *d_x,
+                 const void *d_y, const int32_t *d_row_idx, int batch, float lr, float alpha,
+                 float prior_mean, float prior_rho, int64_t step, uint64_t seed,
+                 const float *d_eps, float *d_cost, void *stream);
+
+/* ---- H2-H5: one HMC proposal (HMC.py:74-104) for P independent chains on the
+ * full training split (d_x, d_y, n_rows).  d_q (P, D) is updated in place when
+ * accepted.  Momentum p = m * z with z from Philox (seed, step, chain) or
+ * d_unit_p (P, D).  h_uniform[P] are the host uniforms of random.random();
+ * burning != 0 forces acceptance.  Outputs (device, float32): d_stats (P, 8) =
+ * {accepted, loss, U0, K0, U1, K1, log_ratio, 0}.  prior_sigma is the raw rho
+ * (negative => NaN potential, every non-burn proposal rejected, HMC.py:149-159). */
+int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const void *d_y,
+                 int n_rows, int L, float epsilon, float m, float prior_mean, float prior_sigma,
+                 int burning, const float *h_uniform, int64_t step, uint64_t seed,
+                 const float *d_unit_p, float *d_stats, void *stream);
+
+/* ---- V2-V4: SVGD.step (SVGD.py:84-141).  d_particles (P_local, D) float32 are
+ * this rank's rows [row0, row0+P_local) of the (M, D) particle matrix; d_all
+ * (M, D) is the matrix the kernel row is evaluated against (== d_particles on
+ * one GPU; the all-gathered snapshot under PYZ_SWEEP_JACOBI).  d_adam_m/v are
+ * the Keras-legacy-Adam slots (P_local, D); t is the 1-based Adam step.  The
+ * RBF kernel and the repulsion sum are accumulated in float64.  gamma > 0 is
+ * the fixed bandwidth (reference: 1.0).  d_loss[0] = sum_i loss_i / M over the
+ * local rows. */
+int pyz_svgd_step(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total,
+                  int row0, float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y,
+                  const int32_t *d_row_idx, int batch, float lr, float gamma, int64_t t, int sweep,
+                  float *d_loss, void *stream);
+
+/* ---- R1: BayesianModel.predict (BayesianModel.py:106-129): S weight draws
+ * d_weights (S, D) -> d_samples (S, n, out) with NaN -> 0, d_mean (n, out). */
+int pyz_predict(pyz_mlp *mlp, const float *d_weights, int n_samples, const float *d_x, int n,
+                float *d_samples, float *d_mean, void *stream);
+
+/* ---- noise: d_out[i] = mean + std * z_i, z from Philox stream (seed, stream, step).
+ * (tf.random.normal at SGLD.py:67, HMC.py:171; tfp samplers at BBB.py:234-237,
+ * SVGD.py:154, distributions/tf/TensorflowProbabilityDistribution.py:55-58.) */
+int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step,
+                    float mean, float std, void *stream);
+
+/* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE Dense kernel of
+ * `layer` on the workspace left by the last pyz_mlp_loss_grad call with the same
+ * arguments.  kind: 0 = forward (G1), 1 = data gradient, 2 = weight gradient (G3).
+ * d_grad (P, D) receives the weight gradient for kind 2. */
+int pyz_bench_dense_kernel(pyz_mlp *mlp, int kind, int layer, const float *d_theta, int n_particles,
+                           const float *d_x, const int32_t *d_row_idx, int batch, float *d_grad,
+                           int iters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYZ_H */

@@ -11,7 +11,7 @@ random numbers: as easy as 1, 2, 3") restated for checking the device stream.
 Stream definition shared with ``csrc/pyz_rng.h``:
     counter = (idx4_lo, idx4_hi, step, stream)   key = (seed_lo, seed_hi)
     element e of a tensor uses idx4 = e // 4 and output word e % 4.
-    u = ((word >> 8) + 0.5) * 2**-24            (exactly representable in fp32)
+    u = ((word >> 9) + 0.5) * 2**-23            (exactly representable in fp32)
     words (0,1) -> (r cos t, r sin t), words (2,3) likewise, with
     r = sqrt(-2 ln u_a), t = 2 pi u_b.
 """
@@ -54,7 +54,7 @@ def words(seed: int, stream: int, step: int, n: int) -> np.ndarray:
 
 
 def _unit(w: np.ndarray) -> np.ndarray:
-    return ((w >> np.uint32(8)).astype(np.float64) + 0.5) * 2.0 ** -24
+    return ((w >> np.uint32(9)).astype(np.float64) + 0.5) * 2.0 ** -23
 
 
 def normal(seed: int, stream: int, step: int, n: int, dtype=np.float64) -> np.ndarray:

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds/loads without a
+GPU and exports exactly the entry points include/pyz.h declares (no compute calls)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pyz.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pyz_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = header_functions()
+    for must in ("pyz_mlp_create", "pyz_mlp_loss_grad", "pyz_sgd_step", "pyz_sgld_step", "pyz_sgld_run", "pyz_bbb_step",
+                 "pyz_hmc_step", "pyz_svgd_step", "pyz_predict", "pyz_fill_normal", "pyz_last_error"):
+        assert must in names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from bayesian_inference_for_nn_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.pyz_version() == 100
+    assert isinstance(lib.pyz_device_count(), int)
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from bayesian_inference_for_nn_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    dims = (ctypes.c_int32 * 2)(4, 2)
+    acts = (ctypes.c_int32 * 1)(9)          # unknown activation
+    rc = lib.pyz_mlp_create(1, dims, acts, 0, 8, 1, ctypes.byref(h))
+    assert rc != 0 and h.value is None
+    assert lib.pyz_last_error()
+    assert lib.pyz_mlp_param_count(None) == -1
+    assert lib.pyz_mlp_destroy(None) == 0
+    with pytest.raises(_lib.PyzError):
+        _lib.check(rc)
+
+
+def test_no_oracle_import_in_the_product_package():
+    pkg = os.path.join(ROOT, "bayesian_inference_for_nn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)

@@ -1,0 +1,363 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on identical
+seeded inputs.  Tolerances: float32 kernels vs the float64 oracle, 1e-4 relative
+to the largest reference magnitude (BASELINE.json north_star); integer labels
+bit-exact."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import bbb as o_bbb
+from oracle import hmc as o_hmc
+from oracle import mlp as o_mlp
+from oracle import philox as o_philox
+from oracle import predict as o_predict
+from oracle import sgd as o_sgd
+from oracle import sgld as o_sgld
+from oracle import svgd as o_svgd
+
+
+def close(gpu, ref, rel=1e-4, what=""):
+    gpu = np.asarray(gpu.detach().cpu().numpy() if hasattr(gpu, "detach") else gpu, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert gpu.shape == ref.shape, (what, gpu.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(gpu - ref).max()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"
+
+
+@pytest.fixture(scope="module")
+def eng(gpu_device):
+    from bayesian_inference_for_nn_amd import engine
+    return engine
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+SPECS = {
+    "tiny_cls": (o_mlp.MLPSpec((5, 7, 3), ("relu", "softmax"), "scce"), 11),
+    "moons": (o_mlp.MLPSpec((2, 50, 2), ("relu", "softmax"), "scce"), 200),
+    "linreg": (o_mlp.MLPSpec((1, 1), ("linear",), "mse"), 64),
+    "reg3": (o_mlp.MLPSpec((4, 6, 6, 2), ("tanh", "sigmoid", "linear"), "mse"), 37),
+    "mnist_small_batch": (o_mlp.MLPSpec((784, 200, 10), ("relu", "softmax"), "scce"), 96),
+    "wide3": (o_mlp.MLPSpec((64, 40, 24, 10), ("relu", "relu", "softmax"), "scce"), 130),
+}
+
+
+def make(spec, n, seed=0, scale=0.3):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(n, spec.dims[0])).astype(np.float32)
+    if spec.loss == "scce":
+        y = rng.integers(0, spec.dims[-1], size=n).astype(np.int32)
+    else:
+        y = rng.normal(size=(n, spec.dims[-1])).astype(np.float32)
+    theta = (rng.normal(size=spec.n_params) * scale).astype(np.float32)
+    return x, y, theta
+
+
+def espec(eng, spec):
+    return eng.MLPSpec(spec.dims, spec.acts, spec.loss)
+
+
+def ydev(spec, y):
+    return dev(y, torch.int32 if spec.loss == "scce" else torch.float32)
+
+
+# ------------------------------------------------------------------ RNG
+def test_device_philox_matches_oracle(eng):
+    from bayesian_inference_for_nn_amd import _lib
+    for n, seed, stream, step in [(1003, 2024, 0, 0), (4096, 7, 3, 12345), (5, (1 << 40) + 9, 1, 2)]:
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        eng.fill_normal(out, seed, stream, step, 0.0, 1.0)
+        ref = o_philox.normal(seed, stream, step, n)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=4e-6)
+    out = torch.empty(200_000, dtype=torch.float32, device="cuda")
+    eng.fill_normal(out, 1, _lib.STREAM_INIT, 0, 0.5, 2.0)
+    z = out.cpu().numpy()
+    assert abs(z.mean() - 0.5) < 0.02 and abs(z.std() - 2.0) < 0.02
+
+
+# ------------------------------------------------------------------ forward / gradient
+@pytest.mark.parametrize("name", list(SPECS))
+def test_loss_grad_and_forward(eng, name):
+    spec, n = SPECS[name]
+    x, y, theta = make(spec, n, seed=sum(map(ord, name)))
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n + 5, max_particles=1)
+    loss, grad = plan.loss_grad(dev(theta), dev(x), ydev(spec, y))
+    rl, rg, rout = o_mlp.loss_and_grad(theta, x, y, spec)
+    close(loss, [rl], what="loss")
+    close(grad[0], rg, what="grad")
+    out = plan.forward(dev(theta), dev(x))
+    close(out[0], rout, what="forward")
+    if spec.loss == "scce":   # integer class labels bit-exact
+        assert np.array_equal(out[0].argmax(1).cpu().numpy(), rout.argmax(1))
+    loss_only, none = plan.loss_grad(dev(theta), dev(x), ydev(spec, y), want_grad=False)
+    assert none is None
+    close(loss_only, [rl], what="loss only")
+    plan.close()
+
+
+def test_particles_and_row_gather(eng):
+    spec, n = SPECS["wide3"]
+    x, y, _ = make(spec, 400, seed=3)
+    rng = np.random.default_rng(5)
+    thetas = (rng.normal(size=(3, spec.n_params)) * 0.3).astype(np.float32)
+    idx = rng.permutation(400)[:n].astype(np.int32)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=256, max_particles=4)
+    loss, grad = plan.loss_grad(dev(thetas), dev(x), ydev(spec, y), batch=n, row_idx=dev(idx, torch.int32))
+    for p in range(3):
+        rl, rg, _ = o_mlp.loss_and_grad(thetas[p], x[idx], y[idx], spec)
+        close(loss[p:p + 1], [rl], what=f"loss[{p}]")
+        close(grad[p], rg, what=f"grad[{p}]")
+    plan.close()
+
+
+def test_full_size_mnist_gradient(eng):
+    """BASELINE config 2 shapes: 784 -> 200 -> 10, batch 1024 (and the ragged 896)."""
+    spec = o_mlp.MLPSpec((784, 200, 10), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(1234)
+    x = rng.random((2048, 784), dtype=np.float32)
+    y = rng.integers(0, 10, size=2048).astype(np.int32)
+    theta = o_mlp.glorot_uniform(spec, np.random.default_rng(99))
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=1024)
+    for b in (1024, 896):
+        idx = rng.permutation(2048)[:b].astype(np.int32)
+        loss, grad = plan.loss_grad(dev(theta), dev(x), dev(y, torch.int32), batch=b, row_idx=dev(idx, torch.int32))
+        rl, rg, _ = o_mlp.loss_and_grad(theta, x[idx], y[idx], spec)
+        close(loss, [rl], what="loss")
+        close(grad[0], rg, what="grad")
+    plan.close()
+
+
+def test_shape_errors_are_reported_not_faulted(eng):
+    from bayesian_inference_for_nn_amd._lib import PyzError
+    spec, n = SPECS["tiny_cls"]
+    x, y, theta = make(spec, 40)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=16)
+    with pytest.raises((PyzError, ValueError)):
+        plan.loss_grad(dev(theta), dev(x), ydev(spec, y))     # 40 rows > max_batch 16
+    bad = eng.MLPSpec((5, 7, 3), ("relu", "relu"), "scce")
+    p2 = eng.MLPPlan(bad, max_batch=16)
+    with pytest.raises(PyzError):
+        p2.loss_grad(dev(theta), dev(x[:8]), ydev(spec, y[:8]))  # SCCE without softmax
+
+
+# ------------------------------------------------------------------ SGD
+def test_sgd_steps_match_oracle(eng):
+    spec = o_mlp.MLPSpec((1, 1), ("linear",), "mse")
+    rng = np.random.default_rng(7)
+    x = (1 + 19 * rng.random((600, 1))).astype(np.float32)
+    y = (2 * x + 2).astype(np.float32)
+    theta0 = np.array([0.3, -0.1], dtype=np.float32)
+    st = o_sgd.SGDState(theta0)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=64)
+    th = dev(theta0)
+    loss = torch.zeros(1, device="cuda")
+    xd, yd = dev(x), dev(y)
+    for s in range(25):
+        idx = rng.permutation(480)[:64].astype(np.int32)
+        plan.sgd_step(th, xd, yd, 1e-3, loss, batch=64, row_idx=dev(idx, torch.int32))
+        rl, _ = o_sgd.sgd_step(st, x[idx], y[idx], spec, 1e-3)
+        close(loss, [rl], what=f"loss step {s}")
+    close(th, st.theta, what="theta")
+
+
+# ------------------------------------------------------------------ SGLD
+@pytest.mark.parametrize("name", ["tiny_cls", "wide3"])
+def test_sgld_step_injected_and_device_noise(eng, name):
+    spec, n = SPECS[name]
+    x, y, theta = make(spec, n, seed=11)
+    D = spec.n_params
+    lr = o_sgld.lr_schedule(100, 0.01, 0.003, 0.99)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n)
+    for device_noise in (False, True):
+        st = o_sgld.SGLDState(theta)
+        th, mean, sq = dev(theta), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        for s in range(6):
+            z = o_philox.normal(2024, 0, s, D)
+            plan.sgld_step(th, mean, sq, dev(x), ydev(spec, y), float(lr(s)), s, 2024, loss,
+                           unit_noise=None if device_noise else dev(z))
+            rl, _ = o_sgld.sgld_step(st, x, y, spec, lr(s), z)
+            close(loss, [rl], what="loss")
+        close(th, st.theta, what="theta")
+        close(mean, st.mean, what="mean")
+        close(sq, st.sq_mean, what="sq_mean")
+    plan.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sgld_run_matches_stepwise_oracle(eng, use_graph):
+    spec = o_mlp.MLPSpec((24, 16, 4), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(21)
+    N, B, n_steps = 150, 64, 19          # 150 rows, batch 64 -> batches 64, 64, 22 per epoch
+    x = rng.normal(size=(N, 24)).astype(np.float32)
+    y = rng.integers(0, 4, size=N).astype(np.int32)
+    theta = (rng.normal(size=spec.n_params) * 0.3).astype(np.float32)
+    idx = np.zeros((n_steps, B), dtype=np.int32)
+    bs, s = [], 0
+    while s < n_steps:
+        perm = rng.permutation(N)
+        for o in range(0, N, B):
+            if s == n_steps:
+                break
+            chunk = perm[o:o + B]
+            idx[s, :len(chunk)] = chunk
+            bs.append(len(chunk))
+            s += 1
+    lr_fn = o_sgld.lr_schedule(n_steps, 0.01, 0.003, 0.99)
+    lrs = [float(np.float32(lr_fn(s))) for s in range(n_steps)]
+    D = spec.n_params
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=B)
+    th, mean, sq = dev(theta), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    losses = torch.zeros(n_steps, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        plan.sgld_run(th, mean, sq, dev(x), dev(y, torch.int32), dev(idx, torch.int32), bs, lrs, 0, 99, losses,
+                      use_graph=use_graph)
+    stream.synchronize()
+    st = o_sgld.SGLDState(theta)
+    ref_losses = []
+    for s in range(n_steps):
+        rows = idx[s, :bs[s]]
+        rl, _ = o_sgld.sgld_step(st, x[rows], y[rows], spec, lrs[s], o_philox.normal(99, 0, s, D))
+        ref_losses.append(rl)
+    close(losses, ref_losses, what="losses")
+    close(th, st.theta, what="theta")
+    close(mean, st.mean, what="mean")
+    close(sq, st.sq_mean, what="sq_mean")
+    plan.close()
+
+
+# ------------------------------------------------------------------ BBB
+@pytest.mark.parametrize("name", ["tiny_cls", "reg3", "wide3"])
+def test_bbb_step_matches_oracle(eng, name):
+    spec, n = SPECS[name]
+    x, y, mu0 = make(spec, n, seed=31)
+    D = spec.n_params
+    rng = np.random.default_rng(32)
+    rho0 = (rng.normal(size=D) * 0.3 - 0.5).astype(np.float32)
+    pm, pr = o_bbb.mix_prior(0.1, 0.8, 0.0, 0.5, 0.7)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n)
+    for device_eps in (False, True):
+        mu, rho, w = dev(mu0), dev(rho0), torch.zeros(D, device="cuda")
+        cost = torch.zeros(4, device="cuda")
+        rmu, rrho = mu0.astype(np.float64), rho0.astype(np.float64)
+        for s in range(1, 5):
+            eps = o_philox.normal(5, 1, s, D)
+            plan.bbb_step(mu, rho, w, dev(x), ydev(spec, y), 1e-2, 0.3, pm, pr, s, 5, cost,
+                          eps=None if device_eps else dev(eps))
+            out = o_bbb.bbb_step(rmu, rrho, eps, x, y, spec, 1e-2, 0.3, pm, pr)
+            rmu, rrho = out["mu"], out["rho"]
+            close(w, out["w"], what="w")
+            c = cost.cpu().numpy()
+            assert abs(c[0] - out["cost"]) <= 1e-4 * abs(out["cost"]) + 1e-5, (c, out["cost"])
+            assert abs(c[1] - out["loss"]) <= 1e-4 * abs(out["loss"]) + 1e-6
+        close(mu, rmu, what="mu")
+        close(rho, rrho, what="rho")
+    plan.close()
+
+
+# ------------------------------------------------------------------ HMC
+@pytest.mark.parametrize("name,L", [("moons", 5), ("linreg", 3), ("tiny_cls", 0)])
+def test_hmc_step_matches_oracle(eng, name, L):
+    spec, n = SPECS[name]
+    x, y, q0 = make(spec, n, seed=41, scale=0.2)
+    D = spec.n_params
+    rng = np.random.default_rng(42)
+    P = 3
+    qs = np.stack([q0 + 0.01 * k for k in range(P)]).astype(np.float32)
+    zs = rng.normal(size=(P, D)).astype(np.float32)
+    eps_, m = 0.002, 0.5
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=P)
+    refs = [o_hmc.hmc_step(qs[c], zs[c], x, y, spec, 0.0, 1.0, L, eps_, m, u=0.5) for c in range(P)]
+    # uniforms chosen away from the acceptance threshold so that fp32 rounding cannot flip the decision
+    us = []
+    for c, r in enumerate(refs):
+        ratio = np.exp(min(r["log_ratio"], 50.0))
+        us.append(0.5 * ratio if c % 2 == 0 else min(2.0 * ratio + 0.1, 1e30))
+    refs = [o_hmc.hmc_step(qs[c], zs[c], x, y, spec, 0.0, 1.0, L, eps_, m, u=us[c]) for c in range(P)]
+    q = dev(qs)
+    stats = torch.zeros((P, 8), device="cuda")
+    plan.hmc_step(q, dev(x), ydev(spec, y), L, eps_, m, 0.0, 1.0, us, 0, 1, stats, unit_p=dev(zs))
+    s = stats.cpu().numpy()
+    for c, r in enumerate(refs):
+        assert bool(s[c, 0]) == r["accepted"], (c, s[c], r["log_ratio"])
+        close(q[c], r["q"], what=f"q[{c}]")
+        for k, key in ((2, "U0"), (3, "K0"), (4, "U1"), (5, "K1")):
+            assert abs(s[c, k] - r[key]) <= 1e-4 * abs(r[key]) + 1e-4, (key, s[c, k], r[key])
+        assert abs(s[c, 6] - r["log_ratio"]) <= 2e-4 * max(abs(r["U0"]), abs(r["K0"]), 1.0)
+        assert abs(s[c, 1] - r["loss"]) <= 1e-4 * abs(r["loss"]) + 1e-6
+    # negative rho: NaN potential -> rejected unless burning; burning accepts
+    q2 = dev(qs)
+    plan.hmc_step(q2, dev(x), ydev(spec, y), L, eps_, m, 0.0, -1.0, [0.0] * P, 0, 1, stats, unit_p=dev(zs))
+    assert (stats[:, 0] == 0).all() and torch.equal(q2, dev(qs))
+    plan.hmc_step(q2, dev(x), ydev(spec, y), L, eps_, m, 0.0, -1.0, [0.0] * P, 0, 1, stats, unit_p=dev(zs), burning=True)
+    assert (stats[:, 0] == 1).all()
+    for c, r in enumerate(refs):
+        close(q2[c], r["q_proposed"], what="burning proposal")
+    plan.close()
+
+
+# ------------------------------------------------------------------ SVGD
+@pytest.mark.parametrize("sweep", ["gauss_seidel", "jacobi"])
+def test_svgd_step_matches_oracle(eng, sweep):
+    spec, n = SPECS["tiny_cls"]
+    x, y, _ = make(spec, n, seed=51)
+    D = spec.n_params
+    rng = np.random.default_rng(52)
+    M = 5
+    parts = (rng.normal(size=(M, D)) * 0.15).astype(np.float32)   # close together: K far from I
+    st = o_svgd.SVGDState(parts)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=M)
+    p = dev(parts)
+    am, av = torch.zeros((M, D), device="cuda"), torch.zeros((M, D), device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    for t in range(1, 4):
+        snapshot = p.clone() if sweep == "jacobi" else p
+        plan.svgd_step(p, snapshot, 0, am, av, dev(x), ydev(spec, y), 0.05, 1.0, t, loss, sweep=sweep)
+        out = o_svgd.svgd_step(st, x, y, spec, 0.05, 1.0, sweep=sweep)
+        close(loss, [out["loss"]], what="loss")
+    close(p, st.particles, what="particles", rel=2e-4)
+    close(am, st.m, what="adam m", rel=2e-4)
+    plan.close()
+
+
+def test_svgd_jacobi_shard_equals_whole(eng):
+    """Rows [2,5) updated as a shard against the gathered matrix == the same rows of a whole-matrix Jacobi step."""
+    spec, n = SPECS["tiny_cls"]
+    x, y, _ = make(spec, n, seed=53)
+    D = spec.n_params
+    parts = (np.random.default_rng(54).normal(size=(5, D)) * 0.15).astype(np.float32)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=5)
+    loss = torch.zeros(1, device="cuda")
+    whole = dev(parts)
+    plan.svgd_step(whole, whole.clone(), 0, torch.zeros((5, D), device="cuda"), torch.zeros((5, D), device="cuda"),
+                   dev(x), ydev(spec, y), 0.05, 1.0, 1, loss, sweep="jacobi")
+    shard = dev(parts[2:5])
+    plan.svgd_step(shard, dev(parts), 2, torch.zeros((3, D), device="cuda"), torch.zeros((3, D), device="cuda"),
+                   dev(x), ydev(spec, y), 0.05, 1.0, 1, loss, sweep="jacobi")
+    close(shard, whole[2:5].cpu().numpy(), rel=1e-6, what="shard rows")
+    plan.close()
+
+
+# ------------------------------------------------------------------ predict
+def test_predict_matches_oracle(eng):
+    for name in ("wide3", "reg3"):
+        spec, n = SPECS[name]
+        x, _, _ = make(spec, n, seed=61)
+        W = (np.random.default_rng(62).normal(size=(7, spec.n_params)) * 0.3).astype(np.float32)
+        W[2, 1] = np.nan
+        plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=3)   # forces chunking over samples
+        samples, mean = plan.predict(dev(W), dev(x))
+        rs, rm = o_predict.predict(W, x, spec)
+        close(samples, rs, what="samples")
+        close(mean, rm, what="mean")
+        if spec.loss == "scce":
+            assert np.array_equal(mean.argmax(1).cpu().numpy(), rm.argmax(1))
+        plan.close()
