@@ -70,6 +70,9 @@ def load():
             raise RuntimeError(
                 "bayesian_inference_for_nn_amd: the HIP library csrc/libpyz.so is missing and could not be built "
                 f"({e}); there is no CPU fallback") from e
+    # torch must be loaded first: libpyz.so then binds to the SAME libamdhip64 instance torch
+    # uses, so that stream handles and device pointers are interchangeable.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree

@@ -42,12 +42,25 @@ FLOP_PER_STEP = 654.5e6        # C2 per grad-step
 BYTES_PER_STEP = 7.03e6
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: the cgroup quota when there is one (a GPU box
+    exposes every core in the affinity mask but grants a share), else the affinity count."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 32)
+
+
 def cpu_baseline(budget_s: float = 12.0):
     """Time the eager CPU restatement (reference op granularity) on a bounded sample."""
     import torch
     from oracle import mlp as o_mlp, torch_eager, sgld as o_sgld
     from bayesian_inference_for_nn_amd import synth
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
     spec = o_mlp.MLPSpec(DIMS, ("relu", "softmax"), "scce")
     x, y = synth.mnist_like(8192)
