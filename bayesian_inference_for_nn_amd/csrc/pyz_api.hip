@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "pyz_common.h"
+#include "pyz_fused.h"
 #include "pyz_gemm.h"
 #include "pyz_kernels.h"
 #include "pyz_rng.h"
@@ -171,6 +172,131 @@ void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, 
   }
 }
 
+// ---- fused path (pyz_fused.h): usable when the last layer fits one 32-wide tile
+inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
+
+void launch_forward_hidden(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
+                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st) {
+  const int L = m->L;
+  m->L = L - 1;  // layers [0, L-1)
+  if (m->L > 0) launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
+  m->L = L;
+}
+
+void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
+                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st) {
+  const int l = m->L - 1;
+  HeadArgs g{};
+  g.K = m->dims[l];
+  g.N = m->dims[l + 1];
+  if (l == 0) {
+    g.hin = x;
+    g.hin_pstride = 0;
+    g.gather_hin = 1;
+  } else {
+    g.hin = m->act[l - 1];
+    g.hin_pstride = (long long)m->max_batch * g.K;
+    g.gather_hin = 0;
+  }
+  g.lda = g.K;
+  g.row_idx = row_idx;
+  g.theta = theta;
+  g.theta_pstride = theta_ps;
+  g.w_off = m->w_off[l];
+  g.loss = m->loss;
+  g.act_last = m->acts[l];
+  g.act_prev = l > 0 ? m->acts[l - 1] : PYZ_ACT_LINEAR;
+  g.vec = (g.K % 8 == 0) && aligned16(g.hin) ? 1 : 0;
+  g.y = y;
+  g.out_last = m->act[l];
+  g.delta_last = want_delta ? m->delta[l] : nullptr;
+  g.delta_prev = (want_delta && l > 0) ? m->delta[l - 1] : nullptr;
+  g.last_pstride = (long long)m->max_batch * g.N;
+  g.prev_pstride = (long long)m->max_batch * g.K;
+  g.part = m->part;
+  g.nblk = cdiv(grid_batch, 32);
+  g.ctl = ctl;
+  m->cur_nblk = g.nblk;
+  hipLaunchKernelGGL(k_head, dim3(g.nblk, P), dim3(256), 0, st, g);
+}
+
+// data gradients of layers L-2 .. 1 (the head already produced delta[L-2])
+void launch_bwd_data_hidden(pyz_mlp *m, const float *theta, long long theta_ps, int P, int grid_batch,
+                            const StepCtl *ctl, hipStream_t st) {
+  for (int l = m->L - 2; l >= 1; --l) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    DenseArgs g{};
+    g.K = K;
+    g.N = N;
+    g.in = m->delta[l];
+    g.in_pstride = (long long)m->max_batch * N;
+    g.lda = N;
+    g.theta = theta;
+    g.theta_pstride = theta_ps;
+    g.w_off = m->w_off[l];
+    g.out = m->delta[l - 1];
+    g.out_pstride = (long long)m->max_batch * K;
+    g.aux = m->act[l - 1];
+    g.aux_pstride = (long long)m->max_batch * K;
+    g.act = m->acts[l - 1];
+    g.vec = (N % 8 == 0) && (m->w_off[l] % 4 == 0) && (P == 1 || theta_ps % 4 == 0) && aligned16(theta) ? 1 : 0;
+    g.ctl = ctl;
+    pyz_launch_bwd_data(g, grid_batch, P, st);
+  }
+}
+
+// every layer's weight gradient in one launch; `a` carries the update mode and its buffers
+void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx, int grid_batch, const StepCtl *ctl,
+                      WgradArgs &a, hipStream_t st) {
+  int tiles = 0;
+  a.L = m->L;
+  for (int l = 0; l < m->L; ++l) {
+    WgradLayer &ly = a.lay[l];
+    ly.K = m->dims[l];
+    ly.N = m->dims[l + 1];
+    if (l == 0) {
+      ly.in = x;
+      ly.in_pstride = 0;
+      ly.gather = 1;
+    } else {
+      ly.in = m->act[l - 1];
+      ly.in_pstride = (long long)m->max_batch * ly.K;
+      ly.gather = 0;
+    }
+    ly.lda = ly.K;
+    ly.delta = m->delta[l];
+    ly.delta_pstride = (long long)m->max_batch * ly.N;
+    ly.w_off = m->w_off[l];
+    ly.tile0 = tiles;
+    tiles += ((ly.K + 1 + 31) / 32) * ((ly.N + 31) / 32);
+  }
+  a.row_idx = row_idx;
+  a.ctl = ctl;
+  a.part = m->part;
+  a.nblk = m->cur_nblk;
+  const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
+  hipLaunchKernelGGL(k_wgrad_all, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, a);
+}
+
+// forward + loss (+ backward into `grad` when upd.mode == NONE and grad given, or the fused update)
+void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
+                          const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
+                          hipStream_t st) {
+  if (can_fuse(m)) {
+    launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
+    launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
+    if (want_grad) {
+      launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
+      launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st);
+    }
+    return;
+  }
+  launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
+  launch_loss(m, P, y, row_idx, grid_batch, ctl, want_grad, st);
+  m->cur_nblk = loss_nblk(m, grid_batch);
+  if (want_grad) launch_backward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, upd.grad, st);
+}
+
 int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
             int slot0 = 0) {
   hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
@@ -251,7 +377,7 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   if (hipMalloc((void **)&m->scal, scal) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "scalar allocation failed"));
   m->ws_bytes += scal;
   {
-    const int rc = need_part(m, (size_t)max_particles * cdiv(max_batch, 256) + 8);
+    const int rc = need_part(m, (size_t)max_particles * cdiv(max_batch, 32) + 8);
     if (rc != PYZ_OK) return fail(rc);
   }
   *out = m;
@@ -304,10 +430,12 @@ int pyz_mlp_loss_grad(pyz_mlp *m, const float *d_theta, int P, const float *d_x,
   if (!d_theta || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   hipStream_t st = as_stream(stream);
   if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
-  launch_forward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, st);
-  launch_loss(m, P, d_y, d_row_idx, batch, m->ctl, d_grad != nullptr, st);
-  if (d_grad) launch_backward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, d_grad, st);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, loss_nblk(m, batch), m->ctl, d_loss);
+  WgradArgs u{};
+  u.mode = PYZ_UPD_NONE;
+  u.grad = d_grad;
+  u.grad_pstride = m->D;
+  launch_loss_backward(m, d_theta, m->D, P, d_x, d_y, d_row_idx, batch, m->ctl, d_grad != nullptr, u, st);
+  hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, d_loss);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -319,14 +447,24 @@ int pyz_sgd_step(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, 
   if (rc) return rc;
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_theta || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
-  if ((rc = need_grad(m, 1))) return rc;
+  const bool fused = can_fuse(m);
+  if (!fused && (rc = need_grad(m, 1))) return rc;
   hipStream_t st = as_stream(stream);
   if ((rc = set_ctl(m, 0, batch, lr, 0, 0, 0, st))) return rc;
-  launch_forward(m, d_theta, m->D, 1, d_x, d_row_idx, batch, m->ctl, st);
-  launch_loss(m, 1, d_y, d_row_idx, batch, m->ctl, true, st);
-  launch_backward(m, d_theta, m->D, 1, d_x, d_row_idx, batch, m->ctl, m->grad, st);
-  hipLaunchKernelGGL(k_sgd_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, m->grad, m->D, m->ctl, m->part,
-                     loss_nblk(m, batch), d_loss);
+  WgradArgs u{};
+  if (fused) {  // the update runs in the epilogue of the weight-gradient kernel
+    u.mode = PYZ_UPD_SGD;
+    u.theta = d_theta;
+    u.loss = d_loss;
+  } else {
+    u.mode = PYZ_UPD_NONE;
+    u.grad = m->grad;
+    u.grad_pstride = m->D;
+  }
+  launch_loss_backward(m, d_theta, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  if (!fused)
+    hipLaunchKernelGGL(k_sgd_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, m->grad, m->D, m->ctl, m->part,
+                       m->cur_nblk, d_loss);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -336,9 +474,28 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
                              uint64_t seed, const float *unit_noise, float *loss, hipStream_t st) {
   const StepCtl *ctl = m->ctl + slot;
-  launch_forward(m, theta, m->D, 1, x, row_idx, grid_batch, ctl, st);
-  launch_loss(m, 1, y, row_idx, grid_batch, ctl, true, st);
-  launch_backward(m, theta, m->D, 1, x, row_idx, grid_batch, ctl, m->grad, st);
+  if (can_fuse(m)) {
+    WgradArgs u{};
+    u.mode = PYZ_UPD_SGLD;
+    u.theta = theta;
+    u.mean = mean;
+    u.sq_mean = sq;
+    u.seed = seed;
+    u.unit_noise = unit_noise;
+    u.loss = loss;
+    u.loss_indexed = chained ? 1 : 0;
+    u.next = chained ? m->ctl + (slot ^ 1) : nullptr;
+    u.tab_bs = m->tab_bs;
+    u.tab_lr = m->tab_lr;
+    u.row_stride = row_stride;
+    launch_loss_backward(m, theta, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st);
+    return;
+  }
+  WgradArgs u{};
+  u.mode = PYZ_UPD_NONE;
+  u.grad = m->grad;
+  u.grad_pstride = m->D;
+  launch_loss_backward(m, theta, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st);
   SgldArgs a{};
   a.theta = theta;
   a.mean = mean;
@@ -353,7 +510,7 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
   a.seed = seed;
   a.unit_noise = unit_noise;
   a.part = m->part;
-  a.nblk = loss_nblk(m, grid_batch);
+  a.nblk = m->cur_nblk;
   a.loss = loss;
   a.loss_indexed = chained ? 1 : 0;
   hipLaunchKernelGGL(k_sgld_update, dim3(cdiv(cdiv(m->D, 4), 256)), dim3(256), 0, st, a);
@@ -367,7 +524,7 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_theta || !d_mean || !d_sq_mean || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   if (n < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
-  if ((rc = need_grad(m, 1))) return rc;
+  if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   hipStream_t st = as_stream(stream);
   if ((rc = set_ctl(m, 0, batch, lr, n, 0, 0, st))) return rc;
   launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, batch, 0, false, 0, seed, d_unit_noise, d_loss, st);
@@ -391,7 +548,7 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
       return pyz_fail(PYZ_E_SHAPE, "batch size %d of step %d outside [1, %d]", h_batch_sizes[s], s, m->max_batch);
     bmax = std::max(bmax, h_batch_sizes[s]);
   }
-  if ((rc = need_grad(m, 1))) return rc;
+  if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   pyz_mlp_full *f = full(m);
   hipStream_t st = as_stream(stream);
   // per-run tables (one padding entry: the last step prepares a slot nobody reads)
@@ -494,9 +651,12 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   a.ctl = m->ctl;
   a.cost = d_cost;
   hipLaunchKernelGGL(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
-  launch_forward(m, d_w, m->D, 1, d_x, d_row_idx, batch, m->ctl, st);
-  launch_loss(m, 1, d_y, d_row_idx, batch, m->ctl, true, st);
-  launch_backward(m, d_w, m->D, 1, d_x, d_row_idx, batch, m->ctl, m->grad, st);
+  WgradArgs u{};
+  u.mode = PYZ_UPD_NONE;
+  u.grad = m->grad;
+  u.grad_pstride = m->D;
+  launch_loss_backward(m, d_w, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  a.nblk_loss = m->cur_nblk;
   hipLaunchKernelGGL(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -536,10 +696,12 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   a.unit_p = d_unit_p;
   a.part = f->x.part2;
   auto grad_eval = [&]() {
-    launch_forward(m, d_q, m->D, P, d_x, nullptr, n_rows, m->ctl, st);
-    launch_loss(m, P, d_y, nullptr, n_rows, m->ctl, true, st);
-    launch_backward(m, d_q, m->D, P, d_x, nullptr, n_rows, m->ctl, m->grad, st);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, loss_nblk(m, n_rows), m->ctl, loss);
+    WgradArgs u{};
+    u.mode = PYZ_UPD_NONE;
+    u.grad = m->grad;
+    u.grad_pstride = m->D;
+    launch_loss_backward(m, d_q, m->D, P, d_x, d_y, nullptr, n_rows, m->ctl, true, u, st);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, loss);
   };
   // momentum, snapshot, K0 and the prior part of U0
   a.nblk = nblk4;
@@ -603,10 +765,14 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
   float *loss = m->scal;  // [n_local]
   if ((rc = set_ctl(m, 0, batch, lr, t, 0, 0, st))) return rc;
   // all loss gradients in one particle-batched pass: g_i depends on particle i only (SVGD.py:104-111)
-  launch_forward(m, d_particles, m->D, n_local, d_x, d_row_idx, batch, m->ctl, st);
-  launch_loss(m, n_local, d_y, d_row_idx, batch, m->ctl, true, st);
-  launch_backward(m, d_particles, m->D, n_local, d_x, d_row_idx, batch, m->ctl, m->grad, st);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, loss_nblk(m, batch), m->ctl, loss);
+  {
+    WgradArgs u{};
+    u.mode = PYZ_UPD_NONE;
+    u.grad = m->grad;
+    u.grad_pstride = m->D;
+    launch_loss_backward(m, d_particles, m->D, n_local, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  }
+  hipLaunchKernelGGL(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, loss);
   SvgdArgs a{};
   a.particles = d_particles;
   a.all = d_all;

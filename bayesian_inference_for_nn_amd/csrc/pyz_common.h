@@ -78,6 +78,7 @@ struct pyz_mlp {
   float *qsave = nullptr;                    // (P, D) HMC snapshot
   double *part = nullptr;                    // reduction partials
   int part_len = 0;
+  int cur_nblk = 0;                          // number of loss partials the last loss launch wrote per particle
   float *scal = nullptr;                     // small device scalars
   StepCtl *ctl = nullptr;                    // device StepCtl
   int32_t *tab_bs = nullptr;                 // per-run tables (device)

@@ -24,6 +24,8 @@
 //     matrices are processed in one launch.
 #pragma once
 
+#include <cstdlib>
+
 #include "pyz_common.h"
 
 struct DenseArgs {
@@ -91,7 +93,84 @@ __device__ __forceinline__ void pyz_tile_epilogue(const f32x16 &acc, float *red,
   }
 }
 
+// ---------------------------------------------------------------- grouped reduction steps
+// The reduction loops are latency-bound (a wave owns a thin slice of a small GEMM), so
+// every loop body first issues the loads of G independent steps and only then runs
+// their MFMAs: G x the memory-level parallelism of a load->use loop.  The cascade
+// G = 8,4,2,1 (or 4,2,1 for float4 steps) handles any trip count without wasted MFMAs.
+template <int G, class L>
+__device__ __forceinline__ void pyz_steps1(int &s, const int se, f32x16 &acc, L load) {
+  for (; s + G <= se; s += G) {
+    float a[G], b[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) load(s + u, a[u], b[u]);
+    __builtin_amdgcn_sched_barrier(0);  // keep every load of the group ahead of its MFMAs
+#pragma unroll
+    for (int u = 0; u < G; ++u) acc = pyz_mfma(a[u], b[u], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <class L>
+__device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load) {
+  pyz_steps1<8>(s, se, acc, load);
+  pyz_steps1<4>(s, se, acc, load);
+  pyz_steps1<2>(s, se, acc, load);
+  pyz_steps1<1>(s, se, acc, load);
+}
+
+template <int G, class L>
+__device__ __forceinline__ void pyz_steps4(int &c, const int ce, f32x16 &acc, L load) {
+  for (; c + G <= ce; c += G) {
+    float4 a[G], b[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) load(c + u, a[u], b[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      acc = pyz_mfma(a[u].x, b[u].x, acc);
+      acc = pyz_mfma(a[u].y, b[u].y, acc);
+      acc = pyz_mfma(a[u].z, b[u].z, acc);
+      acc = pyz_mfma(a[u].w, b[u].w, acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <class L>
+__device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load) {
+  pyz_steps4<8>(c, ce, acc, load);
+  pyz_steps4<4>(c, ce, acc, load);
+  pyz_steps4<2>(c, ce, acc, load);
+  pyz_steps4<1>(c, ce, acc, load);
+}
+
 // ---------------------------------------------------------------- forward
+// acc += sum_k A[k] * W[k][n] (+ bias via the augmented row), this wave's slice of K.
+// ap = this lane's input row, wp = &W[0][n] of this lane's output column.
+__device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap, const float *wp, const int K,
+                                                   const int N, const int vec, const int w, const int S, const int h) {
+  const int c8 = vec ? (K >> 3) : 0;
+  pyz_steps4_all((c8 * w) / S, (c8 * (w + 1)) / S, acc, [&](int c, float4 &a4, float4 &b4) {
+    const int k = 8 * c + 4 * h;
+    a4 = *reinterpret_cast<const float4 *>(ap + k);
+    const float *bp = wp + (long long)k * N;
+    b4 = make_float4(bp[0], bp[N], bp[2 * (long long)N], bp[3 * (long long)N]);
+  });
+  const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
+  pyz_steps1_all((steps * w) / S, (steps * (w + 1)) / S, acc, [&](int s, float &a, float &b) {
+    const int kk = t0 + 2 * s + h;
+    const bool vk = kk < K;
+    const int kc = vk ? kk : 0;
+    const float av = ap[kc], bv = wp[(long long)kc * N];
+    a = vk ? av : 0.0f;
+    b = vk ? bv : 0.0f;
+  });
+  if (w == 0) {  // bias: row K of [W; b] against a column of ones
+    const float a = h == 0 ? 1.0f : 0.0f;
+    const float bv = wp[(long long)K * N];
+    acc = pyz_mfma(a, h == 0 ? bv : 0.0f, acc);
+  }
+}
+
 // out[p][m][n] = act( sum_k in[row(m)][k] * W[k][n] + b[n] ),  m < batch, n < N.
 __global__ void k_dense_fwd(DenseArgs g) {
   extern __shared__ float red[];
@@ -109,38 +188,7 @@ __global__ void k_dense_fwd(DenseArgs g) {
   const float *ap = g.in + p * g.in_pstride + row * g.lda;
   const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
   f32x16 acc = {0};
-  const int c8 = g.vec ? (K >> 3) : 0;
-  {
-    const int cb = (c8 * w) / S, ce = (c8 * (w + 1)) / S;
-#pragma unroll 2
-    for (int c = cb; c < ce; ++c) {
-      const int k = 8 * c + 4 * h;
-      const float4 a4 = *reinterpret_cast<const float4 *>(ap + k);
-      const float *bp = wp + (long long)k * N;
-      const float b0 = bp[0], b1 = bp[N], b2 = bp[2 * (long long)N], b3 = bp[3 * (long long)N];
-      acc = pyz_mfma(a4.x, b0, acc);
-      acc = pyz_mfma(a4.y, b1, acc);
-      acc = pyz_mfma(a4.z, b2, acc);
-      acc = pyz_mfma(a4.w, b3, acc);
-    }
-  }
-  {
-    const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
-    const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
-    for (int s = sb; s < se; ++s) {
-      const int kk = t0 + 2 * s + h;
-      const bool vk = kk < K;
-      const int kc = vk ? kk : 0;
-      const float a = vk ? ap[kc] : 0.0f;
-      const float b = vk ? wp[(long long)kc * N] : 0.0f;
-      acc = pyz_mfma(a, b, acc);
-    }
-  }
-  if (w == 0) {  // bias: row K of [W; b] against a column of ones
-    const float a = h == 0 ? 1.0f : 0.0f;
-    const float b = h == 0 ? wp[(long long)K * N] : 0.0f;
-    acc = pyz_mfma(a, b, acc);
-  }
+  pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h);
   float *op = g.out + p * g.out_pstride;
   const int act = g.act;
   pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
@@ -167,30 +215,21 @@ __global__ void k_dense_bwd_data(DenseArgs g) {
   const float *wp = g.theta + p * g.theta_pstride + g.w_off + (long long)j * N;
   f32x16 acc = {0};
   const int c8 = g.vec ? (N >> 3) : 0;
-  {
-    const int cb = (c8 * w) / S, ce = (c8 * (w + 1)) / S;
-#pragma unroll 2
-    for (int c = cb; c < ce; ++c) {
-      const int k = 8 * c + 4 * h;
-      const float4 a4 = *reinterpret_cast<const float4 *>(ap + k);
-      const float4 b4 = *reinterpret_cast<const float4 *>(wp + k);
-      acc = pyz_mfma(a4.x, b4.x, acc);
-      acc = pyz_mfma(a4.y, b4.y, acc);
-      acc = pyz_mfma(a4.z, b4.z, acc);
-      acc = pyz_mfma(a4.w, b4.w, acc);
-    }
-  }
+  pyz_steps4_all((c8 * w) / S, (c8 * (w + 1)) / S, acc, [&](int c, float4 &a4, float4 &b4) {
+    const int k = 8 * c + 4 * h;
+    a4 = *reinterpret_cast<const float4 *>(ap + k);
+    b4 = *reinterpret_cast<const float4 *>(wp + k);
+  });
   {
     const int t0 = 8 * c8, steps = (N - t0 + 1) >> 1;
-    const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
-    for (int s = sb; s < se; ++s) {
+    pyz_steps1_all((steps * w) / S, (steps * (w + 1)) / S, acc, [&](int s, float &a, float &b) {
       const int kk = t0 + 2 * s + h;
       const bool vk = kk < N;
       const int kc = vk ? kk : 0;
-      const float a = vk ? ap[kc] : 0.0f;
-      const float b = vk ? wp[kc] : 0.0f;
-      acc = pyz_mfma(a, b, acc);
-    }
+      const float av = ap[kc], bv = wp[kc];
+      a = vk ? av : 0.0f;
+      b = vk ? bv : 0.0f;
+    });
   }
   float *op = g.out + p * g.out_pstride;
   const float *hp = g.aux + p * g.aux_pstride;
@@ -208,6 +247,39 @@ __global__ void k_dense_bwd_data(DenseArgs g) {
 // out[p][w_off + i*N + n] = sum_b A(b, i) * delta[p][b][n],  i <= K, n < N, with
 // A(b, i) = in[row(b)][i] for i < K and 1 for i == K (the bias row).
 // `in` = layer input, `aux` = delta (row stride N).
+// With a row gather, the 32 row indices of a 16-step group are fetched by ONE
+// coalesced load (lane j holds the index of batch row 2*s0 + j) and handed to the
+// step that needs them with a lane permute, so no load depends on another load.
+template <int G, bool GATHER>
+__device__ __forceinline__ void pyz_wgrad_steps(int &s, const int se, f32x16 &acc, const float *ap, const float *dp,
+                                                const int32_t *idx, const int lda, const int N, const int batch,
+                                                const int h, const int r, const bool is_w, const bool is_b) {
+  for (; s + G <= se; s += G) {
+    float a[G], d[G];
+    int idxv = 0;
+    if (GATHER) idxv = idx[min(2 * s + r, batch - 1)];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int b = 2 * (s + u) + h;
+      const bool vb = b < batch;
+      const int bc = vb ? b : 0;
+      long long row = bc;
+      if (GATHER) row = __shfl(idxv, 2 * u + h, 64);
+      const float av = ap[row * lda], dv = dp[(long long)bc * N];
+      a[u] = av;
+      d[u] = dv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const bool vb = 2 * (s + u) + h < batch;
+      const float av = vb ? (is_w ? a[u] : (is_b ? 1.0f : 0.0f)) : 0.0f;
+      acc = pyz_mfma(av, vb ? d[u] : 0.0f, acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __global__ void k_dense_bwd_weight(DenseArgs g) {
   extern __shared__ float red[];
   const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -225,18 +297,16 @@ __global__ void k_dense_bwd_weight(DenseArgs g) {
   const int32_t *idx = g.row_idx ? g.row_idx + g.ctl->row_off : nullptr;
   f32x16 acc = {0};
   const int steps = (batch + 1) >> 1;
-  const int sb = (steps * w) / S, se = (steps * (w + 1)) / S;
-#pragma unroll 4
-  for (int s = sb; s < se; ++s) {
-    const int b = 2 * s + h;
-    const bool vb = b < batch;
-    const int bc = vb ? b : 0;
-    const long long row = idx ? (long long)idx[bc] : (long long)bc;
-    float a = ap[row * g.lda];
-    a = is_w ? a : (is_b ? 1.0f : 0.0f);
-    a = vb ? a : 0.0f;
-    const float d = vb ? dp[(long long)bc * N] : 0.0f;
-    acc = pyz_mfma(a, d, acc);
+  int s = (steps * w) / S;
+  const int se = (steps * (w + 1)) / S;
+  if (idx) {
+    pyz_wgrad_steps<16, true>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
+    pyz_wgrad_steps<4, true>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
+    pyz_wgrad_steps<1, true>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
+  } else {
+    pyz_wgrad_steps<16, false>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
+    pyz_wgrad_steps<4, false>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
+    pyz_wgrad_steps<1, false>(s, se, acc, ap, dp, idx, g.lda, N, batch, h, r, is_w, is_b);
   }
   float *op = g.out + p * g.out_pstride + g.w_off;
   pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
@@ -246,9 +316,18 @@ __global__ void k_dense_bwd_weight(DenseArgs g) {
 }
 
 // ---------------------------------------------------------------- launch helpers
+static inline int pyz_env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// waves per workgroup: split the reduction until the launch covers the chip
+// (PYZ_WAVES_TARGET waves) or a wave would get fewer than PYZ_MIN_STEPS MFMA steps.
 static inline int pyz_pick_waves(long long tiles, long long mfma_steps) {
+  static const int target = pyz_env_int("PYZ_WAVES_TARGET", 3072);
+  static const int min_steps = pyz_env_int("PYZ_MIN_STEPS", 8);
   int S = 1;
-  while (S < 16 && tiles * S < 1536 && mfma_steps / (2 * S) >= 6) S *= 2;
+  while (S < 16 && tiles * S < target && mfma_steps / (2 * S) >= min_steps) S *= 2;
   return S;
 }
 
