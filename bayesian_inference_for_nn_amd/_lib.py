@@ -46,6 +46,7 @@ SIGNATURES = {
                                 C.c_int, _p, _p]),
     "pyz_predict": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p, _p, _p]),
     "pyz_fill_normal": (C.c_int, [_p, _i64, _u64, _u32, _u32, _f, _f, _p]),
+    "pyz_debug_stamps": (C.c_int, [C.POINTER(C.c_uint64), _i64]),
     "pyz_bench_dense_kernel": (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_int, _p, _p, C.c_int, _p, C.c_int, _p]),
 }
 

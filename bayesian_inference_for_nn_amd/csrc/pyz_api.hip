@@ -75,7 +75,8 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // forward over all layers; activations land in m->act[l]
 void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
-                    const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st) {
+                    const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st,
+                    float *gather_out = nullptr) {
   for (int l = 0; l < m->L; ++l) {
     DenseArgs g{};
     g.K = m->dims[l];
@@ -84,6 +85,7 @@ void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, c
       g.in = x;
       g.in_pstride = 0;
       g.row_idx = row_idx;
+      g.gather_out = row_idx ? gather_out : nullptr;
     } else {
       g.in = m->act[l - 1];
       g.in_pstride = (long long)m->max_batch * g.K;
@@ -176,10 +178,11 @@ void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, 
 inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
 
 void launch_forward_hidden(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
-                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st) {
+                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st,
+                           float *gather_out) {
   const int L = m->L;
   m->L = L - 1;  // layers [0, L-1)
-  if (m->L > 0) launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
+  if (m->L > 0) launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, gather_out);
   m->L = L;
 }
 
@@ -217,7 +220,8 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   g.nblk = cdiv(grid_batch, 32);
   g.ctl = ctl;
   m->cur_nblk = g.nblk;
-  hipLaunchKernelGGL(k_head, dim3(g.nblk, P), dim3(256), 0, st, g);
+  static const int head_waves = pyz_env_int("PYZ_HEAD_WAVES", 8) >= 8 ? 8 : 4;
+  hipLaunchKernelGGL(k_head, dim3(g.nblk, P), dim3(64 * head_waves), head_waves * 4096 + 2 * 32 * 33 * 4 + 64, st, g);
 }
 
 // data gradients of layers L-2 .. 1 (the head already produced delta[L-2])
@@ -247,7 +251,7 @@ void launch_bwd_data_hidden(pyz_mlp *m, const float *theta, long long theta_ps, 
 
 // every layer's weight gradient in one launch; `a` carries the update mode and its buffers
 void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx, int grid_batch, const StepCtl *ctl,
-                      WgradArgs &a, hipStream_t st) {
+                      WgradArgs &a, hipStream_t st, const float *gathered) {
   int tiles = 0;
   a.L = m->L;
   for (int l = 0; l < m->L; ++l) {
@@ -255,9 +259,9 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
     ly.K = m->dims[l];
     ly.N = m->dims[l + 1];
     if (l == 0) {
-      ly.in = x;
+      ly.in = (row_idx && gathered) ? gathered : x;  // the forward pass left a contiguous copy of the batch rows
       ly.in_pstride = 0;
-      ly.gather = 1;
+      ly.gather = (row_idx && !gathered) ? 1 : 0;
     } else {
       ly.in = m->act[l - 1];
       ly.in_pstride = (long long)m->max_batch * ly.K;
@@ -275,7 +279,14 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   a.part = m->part;
   a.nblk = m->cur_nblk;
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
-  hipLaunchKernelGGL(k_wgrad_all, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, a);
+  const dim3 grid((unsigned)tiles, P);
+  switch (S) {
+    case 1: hipLaunchKernelGGL(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;
+    case 4: hipLaunchKernelGGL(k_wgrad_all<4>, grid, dim3(256), 4 * 4096, st, a); break;
+    case 8: hipLaunchKernelGGL(k_wgrad_all<8>, grid, dim3(512), 8 * 4096, st, a); break;
+    default: hipLaunchKernelGGL(k_wgrad_all<16>, grid, dim3(1024), 16 * 4096, st, a); break;
+  }
 }
 
 // forward + loss (+ backward into `grad` when upd.mode == NONE and grad given, or the fused update)
@@ -283,11 +294,12 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
                           hipStream_t st) {
   if (can_fuse(m)) {
-    launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
+    float *xb = (want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
+    launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb);
     launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
     if (want_grad) {
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
-      launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st);
+      launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xb);
     }
     return;
   }
@@ -371,6 +383,11 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
       return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
     m->ws_bytes += 2 * bytes;
   }
+  {
+    const size_t bytes = sizeof(float) * (size_t)max_batch * m->dims[0] + 64;
+    if (hipMalloc((void **)&m->xb, bytes) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
+    m->ws_bytes += bytes;
+  }
   if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
   if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
   const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
@@ -393,7 +410,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr, m->xb};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) (void)hipHostFree(m->x.tab_host);
@@ -586,7 +603,9 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
   if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0))) return rc;
 
   int s = 0;
-  const int G = 8;  // steps per captured graph (even: the StepCtl ping-pong returns to slot 0)
+  // steps per captured graph (even: the StepCtl ping-pong returns to slot 0); a replay costs a
+  // fixed ~8 us gap, so more steps per graph amortise it
+  static const int G = std::max(2, pyz_env_int("PYZ_GRAPH_STEPS", 32) & ~1);
   if (use_graph && st != nullptr && n_steps >= G) {
     // everything baked into the graph goes into the key
     unsigned long long key = 1469598103934665603ull;
@@ -595,7 +614,7 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
     mix((unsigned long long)(uintptr_t)d_sq_mean); mix((unsigned long long)(uintptr_t)d_x);
     mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
     mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
-    mix((unsigned long long)(uintptr_t)m->tab_bs);
+    mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G);
     if (!m->graph_exec || m->graph_key != key) {
       if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
       if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
@@ -897,6 +916,20 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
   }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
+}
+
+int pyz_debug_stamps(uint64_t *h_out, int64_t n_words) {
+#ifdef PYZ_STAMPS
+  const int64_t total = (int64_t)PYZ_STAMP_KERNELS * PYZ_STAMP_BLOCKS * PYZ_STAMP_WAVES * PYZ_STAMP_SLOTS * 2;
+  if (!h_out || n_words < total) return pyz_fail(PYZ_E_INVALID, "need %lld words", (long long)total);
+  PYZ_HIP(hipDeviceSynchronize());
+  PYZ_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(pyz_dbg_buf), sizeof(unsigned long long) * total));
+  return PYZ_OK;
+#else
+  (void)h_out;
+  (void)n_words;
+  return pyz_fail(PYZ_E_INVALID, "not a PYZ_STAMPS build");
+#endif
 }
 
 }  // extern "C"

@@ -28,6 +28,30 @@ struct StepCtl {
   int32_t slot0;       // first loss / row-table slot of the current run
 };
 
+// ---------------------------------------------------------------- in-kernel stamps (diagnostic build only)
+// -DPYZ_STAMPS builds libpyz_stamps.so: wave 0 of the first 256 workgroups records
+// {s_memtime, s_memrealtime} at phase boundaries.  The shipped library has no stamps.
+#ifdef PYZ_STAMPS
+#define PYZ_STAMP_KERNELS 4
+#define PYZ_STAMP_BLOCKS 64
+#define PYZ_STAMP_WAVES 16
+#define PYZ_STAMP_SLOTS 8
+__device__ unsigned long long pyz_dbg_buf[PYZ_STAMP_KERNELS][PYZ_STAMP_BLOCKS][PYZ_STAMP_WAVES][PYZ_STAMP_SLOTS][2];
+#define PYZ_STAMP(kid, slot)                                                                   \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < PYZ_STAMP_BLOCKS && blockIdx.y == 0) {        \
+      unsigned long long t0_, t1_;                                                             \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(t1_)::"memory"); \
+      pyz_dbg_buf[kid][blockIdx.x][threadIdx.x >> 6][slot][0] = t0_;                          \
+      pyz_dbg_buf[kid][blockIdx.x][threadIdx.x >> 6][slot][1] = t1_;                          \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#else
+#define PYZ_STAMP(kid, slot)
+#endif
+
 // ---------------------------------------------------------------- host errors
 inline std::string &pyz_err_slot() {
   static thread_local std::string s;
@@ -73,6 +97,7 @@ struct pyz_mlp {
   // device workspace (library-owned)
   float *act[PYZ_MAX_LAYERS] = {nullptr};    // output of layer l: (P, max_batch, dims[l+1])
   float *delta[PYZ_MAX_LAYERS] = {nullptr};  // d loss / d pre-activation of layer l, same shape
+  float *xb = nullptr;                       // (max_batch, dims[0]) contiguous copy of the gathered batch rows
   float *grad = nullptr;                     // (P, D)
   float *grad2 = nullptr;                    // (P, D) second scratch (HMC momentum, SVGD phi)
   float *qsave = nullptr;                    // (P, D) HMC snapshot

@@ -41,11 +41,25 @@ struct HeadArgs {
   const StepCtl *ctl;
 };
 
-__global__ void __launch_bounds__(256) k_head(HeadArgs g) {
-  __shared__ float red[4 * 1024];
-  __shared__ float zt[32 * 33];
-  __shared__ float dt[32 * 33];
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+// lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
+__device__ __forceinline__ float pyz_grp8_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64));
+  v = fmaxf(v, __shfl_xor(v, 2, 64));
+  return fmaxf(v, __shfl_xor(v, 4, 64));
+}
+__device__ __forceinline__ float pyz_grp8_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v + __shfl_xor(v, 4, 64);
+}
+
+// blockDim.x = 64 * S with S in {4, 8}; dynamic LDS = S * 4096 + 2 * 32 * 33 * 4 + 64 bytes
+__global__ void __launch_bounds__(512) k_head(HeadArgs g) {
+  extern __shared__ float lds[];
+  PYZ_STAMP(1, 0);
+  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+  float *red = lds, *zt = lds + S * 1024, *dt = zt + 32 * 33;
+  double *lsum = reinterpret_cast<double *>(dt + 32 * 33);  // 4 doubles (8-byte aligned: S*4096 + 8448 bytes)
   const int batch = g.ctl->batch, p = blockIdx.y, m0 = blockIdx.x * 32;
   if (m0 >= batch) {
     if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = 0.0;
@@ -53,6 +67,14 @@ __global__ void __launch_bounds__(256) k_head(HeadArgs g) {
   }
   const int K = g.K, N = g.N;
   const int32_t *idx = g.row_idx ? g.row_idx + g.ctl->row_off : nullptr;
+  // loss-phase inputs (threads 0..255: row = t >> 3), fetched now so their latency hides behind phase 1
+  const int lrow = threadIdx.x >> 3, lsub = threadIdx.x & 7;
+  const int lmm = m0 + lrow;
+  const bool lvalid = threadIdx.x < 256 && lmm < batch;
+  long long yrow = min(lmm, batch - 1);
+  if (idx) yrow = idx[yrow];
+  int ylab = 0;
+  if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
   {
     const int m = min(m0 + r, batch - 1), n = min(r, N - 1);
     long long row = m;
@@ -60,93 +82,118 @@ __global__ void __launch_bounds__(256) k_head(HeadArgs g) {
     const float *ap = g.hin + p * g.hin_pstride + row * g.lda;
     const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
     f32x16 acc = {0};
-    pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, 4, h);
+    PYZ_STAMP(1, 1);
+    pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h);
+    PYZ_STAMP(1, 2);
     float *my = red + w * 1024;
 #pragma unroll
     for (int i = 0; i < 16; ++i) my[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = acc[i];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 1024; e += 256)
-    zt[(e >> 5) * 33 + (e & 31)] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-  __syncthreads();
-  if (threadIdx.x < 64) {  // wave 0; lanes 0..31 own one row each
-    const int mm = m0 + r;
-    const bool valid = (threadIdx.x < 32) && mm < batch;
-    double lm = 0.0;
-    if (threadIdx.x < 32) {
-      const float *z = zt + r * 33;
-      float *d = dt + r * 33;
-      if (valid) {
-        const long long row = idx ? (long long)idx[mm] : (long long)mm;
-        float *ol = g.out_last ? g.out_last + p * g.last_pstride + (long long)mm * N : nullptr;
-        float *dl = g.delta_last ? g.delta_last + p * g.last_pstride + (long long)mm * N : nullptr;
-        if (g.loss == PYZ_LOSS_SCCE) {
-          const int y = reinterpret_cast<const int32_t *>(g.y)[row];
-          float mx = z[0];
-          for (int c = 1; c < N; ++c) mx = fmaxf(mx, z[c]);
-          float se = 0.0f;
-          for (int c = 0; c < N; ++c) se += expf(z[c] - mx);
-          const float lse = mx + logf(se);
-          const float zy = (y >= 0 && y < N) ? z[y] : __builtin_nanf("");
-          lm = (double)(lse - zy);
-          const float inv = 1.0f / (float)batch;
-          for (int c = 0; c < N; ++c) {
-            const float dv = (expf(z[c] - lse) - (c == y ? 1.0f : 0.0f)) * inv;
-            d[c] = dv;
-            if (dl) dl[c] = dv;
-            if (ol) ol[c] = z[c];
-          }
-        } else {
-          const float *y = reinterpret_cast<const float *>(g.y) + row * N;
-          const float sc = 2.0f / ((float)batch * (float)N);
-          float a = 0.0f;
-          for (int c = 0; c < N; ++c) {
-            const float o = pyz_act(z[c], g.act_last);
-            const float e = o - y[c];
-            a += e * e;
-            const float dv = sc * e * pyz_act_grad(o, g.act_last);
-            d[c] = dv;
-            if (dl) dl[c] = dv;
-            if (ol) ol[c] = o;
-          }
-          lm = (double)(a / (float)N);
-        }
-      } else {
-        for (int c = 0; c < N; ++c) d[c] = 0.0f;
-      }
-    }
-    lm = pyz_wave_sum(lm);
-    if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = lm;
+  for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+    float v = red[e];
+    for (int ww = 1; ww < S; ++ww) v += red[ww * 1024 + e];
+    zt[(e >> 5) * 33 + (e & 31)] = v;
   }
-  if (!g.delta_prev) return;
   __syncthreads();
+  PYZ_STAMP(1, 3);
+  // ---- loss rows: 8 lanes per row, classes c = lsub, lsub + 8, ... (N <= 32)
+  if (threadIdx.x < 256) {
+    const float *z = zt + lrow * 33;
+    float *d = dt + lrow * 33;
+    float *ol = g.out_last ? g.out_last + p * g.last_pstride + (long long)lmm * N : nullptr;
+    float *dl = g.delta_last ? g.delta_last + p * g.last_pstride + (long long)lmm * N : nullptr;
+    float zv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zv[q] = (lsub + 8 * q < N) ? z[lsub + 8 * q] : 0.0f;
+    float lm = 0.0f;
+    if (g.loss == PYZ_LOSS_SCCE) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lsub + 8 * q < N) mx = fmaxf(mx, zv[q]);
+      mx = pyz_grp8_max(mx);
+      float se = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lsub + 8 * q < N) se += expf(zv[q] - mx);
+      se = pyz_grp8_sum(se);
+      const float lse = mx + logf(se);
+      const float zy = (ylab >= 0 && ylab < N) ? z[ylab] : __builtin_nanf("");
+      lm = lse - zy;
+      const float inv = 1.0f / (float)batch;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = lsub + 8 * q;
+        if (c < N) {
+          const float dv = lvalid ? (expf(zv[q] - lse) - (c == ylab ? 1.0f : 0.0f)) * inv : 0.0f;
+          d[c] = dv;
+          if (lvalid && dl) dl[c] = dv;
+          if (lvalid && ol) ol[c] = zv[q];
+        }
+      }
+    } else {
+      const float *y = reinterpret_cast<const float *>(g.y) + yrow * N;
+      const float sc = 2.0f / ((float)batch * (float)N);
+      float a = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = lsub + 8 * q;
+        if (c < N) {
+          const float o = pyz_act(zv[q], g.act_last);
+          const float e = o - y[c];
+          a += e * e;
+          const float dv = lvalid ? sc * e * pyz_act_grad(o, g.act_last) : 0.0f;
+          d[c] = dv;
+          if (lvalid && dl) dl[c] = dv;
+          if (lvalid && ol) ol[c] = o;
+        }
+      }
+      lm = pyz_grp8_sum(a) / (float)N;
+    }
+    const double ws = pyz_wave_sum((lvalid && lsub == 0) ? (double)lm : 0.0);
+    if (l == 0) lsum[w] = ws;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+  PYZ_STAMP(1, 4);
+  if (!g.delta_prev) return;
+  // ---- delta_{L-1} tile by tile: (delta_L [32 x N]) (W^T [N x 32]) * act'(h_in)
   const int tiles_j = (K + 31) >> 5;
   const int nsteps = (N + 1) >> 1;
   const float *wl = g.theta + p * g.theta_pstride + g.w_off;
   const float *hp = g.hin + p * g.hin_pstride;
   float *op = g.delta_prev + p * g.prev_pstride;
-  for (int jt = w; jt < tiles_j; jt += 4) {
-    const int j0 = jt * 32, j = min(j0 + r, K - 1);
+  for (int jt = w; jt < tiles_j; jt += S) {
+    const int j0 = jt * 32, jj = j0 + r, j = min(jj, K - 1);
     const float *wp = wl + (long long)j * N;
+    float hv[16];  // act' inputs, fetched with the W operands (one round trip, not 16)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mm = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, batch - 1);
+      hv[i] = hp[(long long)mm * K + j];
+    }
     f32x16 acc = {0};
-    pyz_steps1_all(0, nsteps, acc, [&](int s, float &a, float &b) {
-      const int kk = 2 * s + h;
-      const bool vk = kk < N;
-      const int kc = vk ? kk : 0;
-      const float av = dt[r * 33 + kc], bv = wp[kc];
-      a = vk ? av : 0.0f;
-      b = vk ? bv : 0.0f;
-    });
-    const int jj = j0 + r;
+    pyz_steps1_all(
+        0, nsteps, acc,
+        [&](int s, float &a, float &b) {
+          const int kk = 2 * s + h;
+          const int kc = kk < N ? kk : 0;
+          a = dt[r * 33 + kc];
+          b = wp[kc];
+        },
+        [&](int s, float &a, float &b) {
+          const bool vk = 2 * s + h < N;
+          a = vk ? a : 0.0f;
+          b = vk ? b : 0.0f;
+        });
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int mm = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (mm < batch && jj < K) {
-        const long long o = (long long)mm * K + jj;
-        op[o] = acc[i] * pyz_act_grad(hp[o], g.act_prev);
-      }
+      if (mm < batch && jj < K) op[(long long)mm * K + jj] = acc[i] * pyz_act_grad(hv[i], g.act_prev);
     }
   }
+  PYZ_STAMP(1, 5);
 }
 
 // ---------------------------------------------------------------- all weight gradients + update
@@ -187,19 +234,88 @@ struct WgradArgs {
   long long row_stride;
 };
 
-__global__ void k_wgrad_all(WgradArgs g) {
+// contiguous (no gather) reduction over the batch rows, software pipelined
+__device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *ap, const float *dp, const int lda,
+                                                     const int N, const int batch, int s, const int se, const int h,
+                                                     const bool is_w, const bool is_b) {
+  pyz_steps1_all(
+      s, se, acc,
+      [&](int st, float &a, float &d) {
+        const int bc = min(2 * st + h, batch - 1);
+        a = ap[(long long)bc * lda];
+        d = dp[(long long)bc * N];
+      },
+      [&](int st, float &a, float &d) {
+        const bool vb = 2 * st + h < batch;
+        a = vb ? (is_w ? a : (is_b ? 1.0f : 0.0f)) : 0.0f;
+        d = vb ? d : 0.0f;
+      });
+}
+
+// S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread)
+template <int S>
+__global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   extern __shared__ float red[];
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  PYZ_STAMP(2, 0);
+  constexpr int EPT = 16 / S;  // tile elements per thread in the epilogue
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
+  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   int li = 0;
-  while (li + 1 < g.L && (int)blockIdx.x >= g.lay[li + 1].tile0) ++li;
+  while (li + 1 < g.L && tile >= g.lay[li + 1].tile0) ++li;
   const WgradLayer &ly = g.lay[li];
   const int batch = g.ctl->batch;
   const int K = ly.K, N = ly.N;
   const int tiles_n = (N + 31) >> 5;
-  const int t = blockIdx.x - ly.tile0;
+  const int t = tile - ly.tile0;
   const int i0 = (t / tiles_n) * 32, n0 = (t % tiles_n) * 32;
   const int p = blockIdx.y;
+  const long long w_off = ly.w_off;
+  const int mode = g.mode;
+  const long long nstep = g.ctl->n;
+  const float lr = g.ctl->lr;
+
+  // -- duties of the step that do not depend on this kernel's work: the loss of this step
+  //    (partials written by k_head) and the next step's scalars; one spare wave, at the start
+  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1 && g.loss) {
+    double v = 0.0;
+    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
+    v = pyz_wave_sum(v);
+    if (l == 0) {
+      float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
+      lo[0] = (float)(v / (double)batch);
+      if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
+    }
+  }
+
+  // -- epilogue operands of this thread's elements, fetched before the reduction so that
+  //    their latency (and the Philox arithmetic) hides behind the operand loads / MFMAs
+  long long ee[EPT];
+  bool ev[EPT];
+  float th0[EPT], mu0[EPT], sq0[EPT], zz[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    int ro, co;
+    if (S == 1) {
+      ro = (q & 3) + 8 * (q >> 2) + 4 * h;
+      co = r;
+    } else {
+      const int e = threadIdx.x + q * 64 * S;
+      ro = e >> 5;
+      co = e & 31;
+    }
+    const int ii = i0 + ro, nn = n0 + co;
+    ev[q] = ii <= K && nn < N;
+    ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
+    th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
+    if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
+    if (mode == PYZ_UPD_SGLD) {
+      mu0[q] = g.mean[ee[q]];
+      sq0[q] = g.sq_mean[ee[q]];
+      if (g.unit_noise) zz[q] = g.unit_noise[ee[q]];
+    }
+  }
+
   const int i = i0 + r, n = min(n0 + r, N - 1);
   const int ic = min(i, K - 1);
   const bool is_w = i < K, is_b = i == K;
@@ -210,47 +326,58 @@ __global__ void k_wgrad_all(WgradArgs g) {
   const int steps = (batch + 1) >> 1;
   int s = (steps * w) / S;
   const int se = (steps * (w + 1)) / S;
+  PYZ_STAMP(2, 1);
   if (idx) {
     pyz_wgrad_steps<16, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
     pyz_wgrad_steps<4, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
     pyz_wgrad_steps<1, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
   } else {
-    pyz_wgrad_steps<16, false>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
-    pyz_wgrad_steps<4, false>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
-    pyz_wgrad_steps<1, false>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
+    pyz_wgrad_accumulate(acc, ap, dp, ly.lda, N, batch, s, se, h, is_w, is_b);
   }
-  const long long w_off = ly.w_off;
-  const int mode = g.mode;
-  const float lr = g.ctl->lr;
-  const long long nstep = g.ctl->n;
-  pyz_tile_epilogue(acc, red, [&](int ro, int co, float gv) {
-    const int ii = i0 + ro, nn = n0 + co;
-    if (ii > K || nn >= N) return;
-    const long long e = w_off + (long long)ii * N + nn;
-    if (mode == PYZ_UPD_NONE) {
-      g.grad[p * g.grad_pstride + e] = gv;
-    } else if (mode == PYZ_UPD_SGD) {
-      g.theta[e] = g.theta[e] - lr * gv;
-    } else {
-      float z;
-      if (g.unit_noise) {
-        z = g.unit_noise[e];
-      } else {
-        const float4 q = pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(e >> 2));
-        const int k = (int)(e & 3);
-        z = k == 0 ? q.x : (k == 1 ? q.y : (k == 2 ? q.z : q.w));
-      }
-      const float fn = (float)nstep, fn1 = fn + 1.0f;
-      const float noise = lr * z;
-      const float th = g.theta[e] + (-lr) * (gv + noise);
-      g.theta[e] = th;
-      g.mean[e] = (g.mean[e] * fn + th) / fn1;
-      g.sq_mean[e] = (g.sq_mean[e] * fn + th * th) / fn1;
+  if (mode == PYZ_UPD_SGLD && !g.unit_noise) {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const float4 nq = pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2));
+      const int k = (int)(ee[q] & 3);
+      zz[q] = k == 0 ? nq.x : (k == 1 ? nq.y : (k == 2 ? nq.z : nq.w));
     }
-  });
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g.loss) {
-    float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
-    lo[0] = (float)(pyz_sum_partials(g.part, g.nblk) / (double)batch);
-    if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
   }
+  PYZ_STAMP(2, 2);
+  float gv[EPT];
+  if (S == 1) {
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) gv[q] = acc[q];
+  } else {
+    float *my = red + w * 1024;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) my[((q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = threadIdx.x + q * 64 * S;
+      float v = red[e];
+#pragma unroll
+      for (int ww = 1; ww < S; ++ww) v += red[ww * 1024 + e];
+      gv[q] = v;
+    }
+  }
+  PYZ_STAMP(2, 4);
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    if (!ev[q]) continue;
+    const long long e = ee[q];
+    if (mode == PYZ_UPD_NONE) {
+      g.grad[p * g.grad_pstride + e] = gv[q];
+    } else if (mode == PYZ_UPD_SGD) {
+      g.theta[e] = th0[q] - lr * gv[q];
+    } else {
+      const float fn = (float)nstep, fn1 = fn + 1.0f;
+      const float noise = lr * zz[q];
+      const float th = th0[q] + (-lr) * (gv[q] + noise);
+      g.theta[e] = th;
+      g.mean[e] = (mu0[q] * fn + th) / fn1;
+      g.sq_mean[e] = (sq0[q] * fn + th * th) / fn1;
+    }
+  }
+  PYZ_STAMP(2, 3);
 }

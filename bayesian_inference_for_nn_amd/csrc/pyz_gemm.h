@@ -44,7 +44,18 @@ struct DenseArgs {
   int vec;                    // float4 loads legal along the reduction axis
   const StepCtl *ctl;         // batch (rows) and row-index offset of this step
   const int32_t *row_idx;     // optional gather of `in` rows (layer 0 only)
+  float *gather_out;          // optional (max_batch, K): contiguous copy of the gathered rows (forward, layer 0)
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids
+// b and b+8 share an L2.  Give every XCD a CONTIGUOUS range of tile ids instead: tiles
+// that share operand panels (the same batch rows / the same weight columns) then hit one
+// L2 instead of pulling the panel through the fabric eight times.  Bijective for any n;
+// placement only changes speed, never results.
+__device__ __forceinline__ int pyz_xcd_remap(const int bid, const int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7, local = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + local;
+}
 
 __device__ __forceinline__ f32x16 pyz_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -93,92 +104,154 @@ __device__ __forceinline__ void pyz_tile_epilogue(const f32x16 &acc, float *red,
   }
 }
 
-// ---------------------------------------------------------------- grouped reduction steps
-// The reduction loops are latency-bound (a wave owns a thin slice of a small GEMM), so
-// every loop body first issues the loads of G independent steps and only then runs
-// their MFMAs: G x the memory-level parallelism of a load->use loop.  The cascade
-// G = 8,4,2,1 (or 4,2,1 for float4 steps) handles any trip count without wasted MFMAs.
-template <int G, class L>
-__device__ __forceinline__ void pyz_steps1(int &s, const int se, f32x16 &acc, L load) {
-  for (; s + G <= se; s += G) {
-    float a[G], b[G];
-#pragma unroll
-    for (int u = 0; u < G; ++u) load(s + u, a[u], b[u]);
-    __builtin_amdgcn_sched_barrier(0);  // keep every load of the group ahead of its MFMAs
-#pragma unroll
-    for (int u = 0; u < G; ++u) acc = pyz_mfma(a[u], b[u], acc);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-template <class L>
-__device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load) {
-  pyz_steps1<8>(s, se, acc, load);
-  pyz_steps1<4>(s, se, acc, load);
-  pyz_steps1<2>(s, se, acc, load);
-  pyz_steps1<1>(s, se, acc, load);
-}
+// ---------------------------------------------------------------- pipelined reduction steps
+// The reduction loops are latency-bound (a wave owns a thin slice of a small GEMM) and
+// the MFMA pipe of a SIMD is shared by up to four such waves.  Each loop is therefore a
+// two-stage software pipeline over groups of G steps: the loads of group g+1 are issued
+// before the MFMAs of group g, with scheduling barriers so the compiler cannot sink a
+// load below the MFMAs it should overlap.  `load(step, a, b)` only loads (no arithmetic
+// on the result, which would force an early wait); `fix(step, a, b)` masks at MFMA time.
+// The last group clamps its loads to the last step and skips the MFMAs past the end.
+struct PyzNoFix {
+  __device__ __forceinline__ void operator()(int, float &, float &) const {}
+};
 
-template <int G, class L>
-__device__ __forceinline__ void pyz_steps4(int &c, const int ce, f32x16 &acc, L load) {
-  for (; c + G <= ce; c += G) {
-    float4 a[G], b[G];
+template <int G, class L, class F>
+__device__ __forceinline__ void pyz_pipe1(int s, const int se, f32x16 &acc, L load, F fix) {
+  if (s >= se) return;
+  float an[G], bn[G], a[G], b[G];
+  const int last = se - 1;
 #pragma unroll
-    for (int u = 0; u < G; ++u) load(c + u, a[u], b[u]);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < G; ++u) load(min(s + u, last), an[u], bn[u]);
+  for (;;) {
+    // the copy is the wait for the loads issued one group ago; a single-phase loop keeps
+    // the compiler's vmcnt bookkeeping exact (a ping-pong body drains at the back edge)
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      acc = pyz_mfma(a[u].x, b[u].x, acc);
-      acc = pyz_mfma(a[u].y, b[u].y, acc);
-      acc = pyz_mfma(a[u].z, b[u].z, acc);
-      acc = pyz_mfma(a[u].w, b[u].w, acc);
+      a[u] = an[u];
+      b[u] = bn[u];
+    }
+    const int sn = s + G;
+    if (sn < se) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) load(min(sn + u, last), an[u], bn[u]);
     }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (s + u < se) {
+        fix(s + u, a[u], b[u]);
+        acc = pyz_mfma(a[u], b[u], acc);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    s = sn;
+    if (s >= se) break;
   }
 }
-template <class L>
-__device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load) {
-  pyz_steps4<8>(c, ce, acc, load);
-  pyz_steps4<4>(c, ce, acc, load);
-  pyz_steps4<2>(c, ce, acc, load);
-  pyz_steps4<1>(c, ce, acc, load);
+
+#define PYZ_MFMA4(A, B)              \
+  acc = pyz_mfma((A).x, (B).x, acc); \
+  acc = pyz_mfma((A).y, (B).y, acc); \
+  acc = pyz_mfma((A).z, (B).z, acc); \
+  acc = pyz_mfma((A).w, (B).w, acc);
+
+// float4 steps: one step = 8 reduction indices = four MFMAs
+struct PyzNoUse4 {
+  __device__ __forceinline__ void operator()(int, const float4 &) const {}
+};
+
+template <int G, class L, class U>
+__device__ __forceinline__ void pyz_pipe4(int c, const int ce, f32x16 &acc, L load, U use) {
+  if (c >= ce) return;
+  float4 an[G], bn[G], a[G], b[G];
+  const int last = ce - 1;
+#pragma unroll
+  for (int u = 0; u < G; ++u) load(min(c + u, last), an[u], bn[u]);
+  for (;;) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      a[u] = an[u];
+      b[u] = bn[u];
+    }
+    const int cn = c + G;
+    if (cn < ce) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) load(min(cn + u, last), an[u], bn[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (c + u < ce) {
+        use(c + u, a[u]);
+        PYZ_MFMA4(a[u], b[u])
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    c = cn;
+    if (c >= ce) break;
+  }
+}
+
+template <class L, class U>
+__device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load, U use) {
+  pyz_pipe4<2>(c, ce, acc, load, use);
+}
+template <class L, class F>
+__device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load, F fix) {
+  pyz_pipe1<8>(s, se, acc, load, fix);
 }
 
 // ---------------------------------------------------------------- forward
 // acc += sum_k A[k] * W[k][n] (+ bias via the augmented row), this wave's slice of K.
 // ap = this lane's input row, wp = &W[0][n] of this lane's output column.
+// gp (optional) = this lane's row of the gathered-batch copy: the A values are stored
+// there once they have arrived (at MFMA time, so the store never stalls the load phase).
 __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap, const float *wp, const int K,
-                                                   const int N, const int vec, const int w, const int S, const int h) {
+                                                   const int N, const int vec, const int w, const int S, const int h,
+                                                   float *gp = nullptr) {
+  const float bias = wp[(long long)K * N];  // issued first, consumed last
   const int c8 = vec ? (K >> 3) : 0;
-  pyz_steps4_all((c8 * w) / S, (c8 * (w + 1)) / S, acc, [&](int c, float4 &a4, float4 &b4) {
-    const int k = 8 * c + 4 * h;
-    a4 = *reinterpret_cast<const float4 *>(ap + k);
-    const float *bp = wp + (long long)k * N;
-    b4 = make_float4(bp[0], bp[N], bp[2 * (long long)N], bp[3 * (long long)N]);
-  });
+  pyz_steps4_all(
+      (c8 * w) / S, (c8 * (w + 1)) / S, acc,
+      [&](int c, float4 &a4, float4 &b4) {
+        const int k = 8 * c + 4 * h;
+        a4 = *reinterpret_cast<const float4 *>(ap + k);
+        const float *bp = wp + (long long)k * N;
+        b4 = make_float4(bp[0], bp[N], bp[2 * (long long)N], bp[3 * (long long)N]);
+      },
+      [&](int c, const float4 &a4) {
+        if (gp) *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
+      });
   const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
-  pyz_steps1_all((steps * w) / S, (steps * (w + 1)) / S, acc, [&](int s, float &a, float &b) {
-    const int kk = t0 + 2 * s + h;
-    const bool vk = kk < K;
-    const int kc = vk ? kk : 0;
-    const float av = ap[kc], bv = wp[(long long)kc * N];
-    a = vk ? av : 0.0f;
-    b = vk ? bv : 0.0f;
-  });
+  pyz_steps1_all(
+      (steps * w) / S, (steps * (w + 1)) / S, acc,
+      [&](int s, float &a, float &b) {
+        const int kk = t0 + 2 * s + h;
+        const int kc = kk < K ? kk : 0;
+        a = ap[kc];
+        b = wp[(long long)kc * N];
+      },
+      [&](int s, float &a, float &b) {
+        const int kk = t0 + 2 * s + h;
+        const bool vk = kk < K;
+        if (gp && vk) gp[kk] = a;
+        a = vk ? a : 0.0f;
+        b = vk ? b : 0.0f;
+      });
   if (w == 0) {  // bias: row K of [W; b] against a column of ones
-    const float a = h == 0 ? 1.0f : 0.0f;
-    const float bv = wp[(long long)K * N];
-    acc = pyz_mfma(a, h == 0 ? bv : 0.0f, acc);
+    acc = pyz_mfma(h == 0 ? 1.0f : 0.0f, h == 0 ? bias : 0.0f, acc);
   }
 }
 
 // out[p][m][n] = act( sum_k in[row(m)][k] * W[k][n] + b[n] ),  m < batch, n < N.
 __global__ void k_dense_fwd(DenseArgs g) {
   extern __shared__ float red[];
+  PYZ_STAMP(0, 0);
   const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int batch = g.ctl->batch;
   const int tiles_n = (g.N + 31) >> 5;
-  const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   if (m0 >= batch) return;  // uniform per workgroup
   const int p = blockIdx.y;
   const int K = g.K, N = g.N;
@@ -188,13 +261,17 @@ __global__ void k_dense_fwd(DenseArgs g) {
   const float *ap = g.in + p * g.in_pstride + row * g.lda;
   const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
   f32x16 acc = {0};
-  pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h);
+  PYZ_STAMP(0, 1);
+  float *gp = (g.gather_out && n0 == 0 && p == 0) ? g.gather_out + (long long)m * K : nullptr;
+  pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h, gp);
+  PYZ_STAMP(0, 2);
   float *op = g.out + p * g.out_pstride;
   const int act = g.act;
   pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
     const int mm = m0 + ro, nn = n0 + co;
     if (mm < batch && nn < N) op[(long long)mm * N + nn] = pyz_act(v, act);
   });
+  PYZ_STAMP(0, 3);
 }
 
 // ---------------------------------------------------------------- data gradient
@@ -207,7 +284,8 @@ __global__ void k_dense_bwd_data(DenseArgs g) {
   const int batch = g.ctl->batch;
   const int K = g.K, N = g.N;
   const int tiles_j = (K + 31) >> 5;
-  const int m0 = (blockIdx.x / tiles_j) * 32, j0 = (blockIdx.x % tiles_j) * 32;
+  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_j) * 32, j0 = (tile % tiles_j) * 32;
   if (m0 >= batch) return;
   const int p = blockIdx.y;
   const int m = min(m0 + r, batch - 1), j = min(j0 + r, K - 1);
@@ -215,21 +293,29 @@ __global__ void k_dense_bwd_data(DenseArgs g) {
   const float *wp = g.theta + p * g.theta_pstride + g.w_off + (long long)j * N;
   f32x16 acc = {0};
   const int c8 = g.vec ? (N >> 3) : 0;
-  pyz_steps4_all((c8 * w) / S, (c8 * (w + 1)) / S, acc, [&](int c, float4 &a4, float4 &b4) {
-    const int k = 8 * c + 4 * h;
-    a4 = *reinterpret_cast<const float4 *>(ap + k);
-    b4 = *reinterpret_cast<const float4 *>(wp + k);
-  });
+  pyz_steps4_all(
+      (c8 * w) / S, (c8 * (w + 1)) / S, acc,
+      [&](int c, float4 &a4, float4 &b4) {
+        const int k = 8 * c + 4 * h;
+        a4 = *reinterpret_cast<const float4 *>(ap + k);
+        b4 = *reinterpret_cast<const float4 *>(wp + k);
+      },
+      PyzNoUse4());
   {
     const int t0 = 8 * c8, steps = (N - t0 + 1) >> 1;
-    pyz_steps1_all((steps * w) / S, (steps * (w + 1)) / S, acc, [&](int s, float &a, float &b) {
-      const int kk = t0 + 2 * s + h;
-      const bool vk = kk < N;
-      const int kc = vk ? kk : 0;
-      const float av = ap[kc], bv = wp[kc];
-      a = vk ? av : 0.0f;
-      b = vk ? bv : 0.0f;
-    });
+    pyz_steps1_all(
+        (steps * w) / S, (steps * (w + 1)) / S, acc,
+        [&](int s, float &a, float &b) {
+          const int kk = t0 + 2 * s + h;
+          const int kc = kk < N ? kk : 0;
+          a = ap[kc];
+          b = wp[kc];
+        },
+        [&](int s, float &a, float &b) {
+          const bool vk = t0 + 2 * s + h < N;
+          a = vk ? a : 0.0f;
+          b = vk ? b : 0.0f;
+        });
   }
   float *op = g.out + p * g.out_pstride;
   const float *hp = g.aux + p * g.aux_pstride;
@@ -287,7 +373,8 @@ __global__ void k_dense_bwd_weight(DenseArgs g) {
   const int batch = g.ctl->batch;
   const int K = g.K, N = g.N;
   const int tiles_n = (N + 31) >> 5;
-  const int i0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
+  const int i0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   const int p = blockIdx.y;
   const int i = i0 + r, n = min(n0 + r, N - 1);
   const int ic = min(i, K - 1);

@@ -108,7 +108,7 @@ int pyz_sgld_step(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean,
  * without per-step host work): step s in [0, n_steps) uses rows
  * d_row_idx[(slot0+s)*max_batch .. +h_batch_sizes[s]) of the resident data set,
  * learning rate h_lr[s] and count n0+s, and writes its batch loss to
- * d_losses[slot0+s].  With use_graph != 0 (and a non-NULL stream) eight steps are
+ * d_losses[slot0+s].  With use_graph != 0 (and a non-NULL stream) 32 steps are
  * captured once into a hipGraph and replayed; the per-step scalars live in device
  * memory and are advanced by the last kernel of each step. */
 int pyz_sgld_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x,
@@ -169,6 +169,11 @@ int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, 
 int pyz_bench_dense_kernel(pyz_mlp *mlp, int kind, int layer, const float *d_theta, int n_particles,
                            const float *d_x, const int32_t *d_row_idx, int batch, float *d_grad,
                            int iters, void *stream);
+
+/* ---- diagnostic build only (-DPYZ_STAMPS, csrc/libpyz_stamps.so): copy the in-kernel
+ * phase stamps {shader clock, 100 MHz clock} x 8 slots x 256 workgroups x 4 kernels to
+ * h_out (uint64).  The shipped library returns PYZ_E_INVALID. */
+int pyz_debug_stamps(uint64_t *h_out, int64_t n_words);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): build csrc/libpyz_stamps.so with -DPYZ_STAMPS, run a few SGLD steps of
+the headline configuration and print where wave 0 of each workgroup spends its time.
+Never used for reported numbers (the stamps forbid overlaps the real kernels have)."""
+import ctypes as C
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "bayesian_inference_for_nn_amd", "csrc")
+lib = os.path.join(csrc, "libpyz_stamps.so")
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPYZ_STAMPS",
+                       "-Wno-unused-function", "-Wno-pass-failed", "pyz_api.hip", "-o", lib], cwd=csrc)
+from bayesian_inference_for_nn_amd import _build
+_build.LIB = lib
+_build.build = lambda *a, **k: lib
+import torch
+from bayesian_inference_for_nn_amd import engine, synth, _lib
+DIMS = (784, 200, 10)
+spec = engine.MLPSpec(DIMS, ("relu", "softmax"), "scce")
+plan = engine.MLPPlan(spec, max_batch=1024)
+x_h, y_h = synth.mnist_like(48000)
+x, y = torch.as_tensor(x_h).cuda(), torch.as_tensor(y_h).cuda()
+D = spec.n_params
+theta = torch.as_tensor(synth.glorot_uniform(DIMS)).cuda()
+mean, sq = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+n = 64
+idx_h, sizes = synth.batch_plan(48000, 1024, n)
+idx = torch.as_tensor(idx_h).cuda()
+lrs = synth.sgld_lr_table(n, 0.01, 0.003, 0.99, 0, n)
+losses = torch.zeros(n, device="cuda")
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    for rep in range(3):
+        plan.sgld_run(theta, mean, sq, x, y, idx, sizes, lrs, 0, 1, losses, use_graph=True)
+st.synchronize()
+K, B, W, S = 4, 64, 16, 8
+buf = (C.c_uint64 * (K * B * W * S * 2))()
+_lib.check(_lib.load().pyz_debug_stamps(buf, K * B * W * S * 2))
+a = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)
+names = {0: ("k_dense_fwd", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "end")], 64, 16),
+         1: ("k_head", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "lds combined"), (4, "loss rows done"), (5, "end")], 32, 8),
+         2: ("k_wgrad_all", [(0, "start"), (1, "addr+prefetch issued"), (2, "accumulate done"), (4, "tile reduced"), (3, "end")], 64, 16)}
+for k, (nm, slots, nb, nw) in names.items():
+    t = a[k, :nb, :nw, :, 1] * 10.0          # ns, [block, wave, slot]
+    cyc = a[k, :nb, :nw, :, 0]
+    t0 = t[:, :, 0].min(axis=1, keepdims=True)  # block start = earliest wave start
+    print(f"== {nm}: {nb} workgroups x {nw} waves; times in ns since the workgroup's first wave started")
+    clk = np.median((cyc[:, 0, slots[-1][0]] - cyc[:, 0, 0]) / np.maximum(t[:, 0, slots[-1][0]] - t[:, 0, 0], 1))
+    print(f"   clock {clk:.2f} GHz")
+    for sl, label in slots:
+        rel = t[:, :, sl] - t0
+        per_wave = np.median(rel, axis=0)
+        print(f"   {label:22s} median over waves {np.median(rel):7.0f}  min-wave {per_wave.min():7.0f}  max-wave {per_wave.max():7.0f}   per wave: "
+              + " ".join(f"{v:5.0f}" for v in per_wave))
