@@ -1,0 +1,48 @@
+"""Wrapper that turns a vector distribution into a result ``Distribution``
+(mirrors Pyesian/distributions/tf/TensorflowProbabilityDistribution.py:9-58; the wrapped
+object is one of distributions/tfd.py since TensorFlow-Probability is not a dependency)."""
+
+import json
+import os
+
+import numpy as np
+
+from .. import tfd
+from ..Distribution import Distribution
+
+
+class TensorflowProbabilityDistribution(Distribution):
+    def __init__(self, tf_distribution):
+        self._tf_distribution = tf_distribution
+        if len(tf_distribution.batch_shape) + len(tf_distribution.event_shape) != 1:
+            raise ValueError('The provided tensorflow distribution should be a vector')
+        size = tf_distribution.event_shape[0] if len(tf_distribution.event_shape) >= 1 else tf_distribution.batch_shape[0]
+        super().__init__(size)
+
+    def sample(self):
+        self._tf_distribution.sample()            # the reference draws twice and keeps the second (:55-58)
+        return self._tf_distribution.sample()
+
+    def sample_n(self, n: int):
+        d = self._tf_distribution
+        if isinstance(d, tfd.Deterministic):
+            return np.repeat(d.loc[None, :], n, axis=0)
+        return np.stack([self.sample() for _ in range(n)])
+
+    def store(self, path: str):
+        d = self._tf_distribution
+        data = {"type": type(d).__name__, "loc": np.asarray(d.loc).tolist()}
+        if isinstance(d, tfd.Normal):
+            data["scale"] = np.asarray(d.scale).tolist()
+        with open(os.path.join(path, "distribution.json"), "w") as f:
+            f.write(json.dumps(data))
+
+    @classmethod
+    def load(cls, path: str) -> "Distribution":
+        with open(os.path.join(path, "distribution.json"), "r") as f:
+            data = json.load(f)
+        if data["type"] == "Normal":
+            return cls(tfd.Normal(np.asarray(data["loc"], np.float32), np.asarray(data["scale"], np.float32)))
+        if data["type"] == "Deterministic":
+            return cls(tfd.Deterministic(np.asarray(data["loc"], np.float32)))
+        raise ValueError("unknown distribution type " + str(data["type"]))

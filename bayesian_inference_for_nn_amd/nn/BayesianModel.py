@@ -1,0 +1,160 @@
+"""Result container of every optimizer: a model + per-layer-interval weight distributions,
+Monte-Carlo ``predict``, directory ``store`` / ``load``
+(mirrors Pyesian/nn/BayesianModel.py:10-203; the read-out is batched on the GPU:
+all ``nb_samples`` weight draws go through one particle-batched forward, pyz_predict)."""
+
+from __future__ import annotations
+
+import json
+import os
+import shutil
+
+import numpy as np
+
+from .model import Array, DenseNet, model_from_json
+
+
+class BayesianModel:
+    def __init__(self, model_config: str):
+        self._model_config = model_config
+        model: DenseNet = model_from_json(model_config)
+        self._n_layers = len(model.layers)
+        self._layers_dtbn_intervals = []
+        self._distributions = []
+        self._model = model
+        self._plan = None
+
+    # ------------------------------------------------------------------ distributions
+    def apply_distribution(self, distribution, start_layer: int, end_layer: int):
+        """Insertion rule of BayesianModel.py:25-48, as written: the first interval is appended;
+        a later one is inserted after the first stored interval whose start is smaller; an
+        interval that is not greater than any stored start is silently dropped."""
+        if start_layer > end_layer:
+            raise ValueError('starting_layer must be less than end_layer')
+        elif start_layer < 0 or end_layer >= self._n_layers:
+            raise ValueError('out of bounds')
+        interval = [start_layer, end_layer]
+        if len(self._layers_dtbn_intervals) == 0:
+            self._layers_dtbn_intervals.append(interval)
+            self._distributions.append(distribution)
+            return
+        for i in range(len(self._layers_dtbn_intervals)):
+            if start_layer > self._layers_dtbn_intervals[i][0]:
+                self._layers_dtbn_intervals = self._layers_dtbn_intervals[:i + 1] + [interval] + \
+                    self._layers_dtbn_intervals[i + 1:]
+                self._distributions = self._distributions[:i + 1] + [distribution] + self._distributions[i + 1:]
+                break
+
+    def apply_distributions_layers(self, layer_list, dtbn_list):
+        self._layers_dtbn_intervals = layer_list
+        self._distributions = dtbn_list
+
+    # ------------------------------------------------------------------ sampling
+    def _interval_slices(self):
+        """flat slice of the parameters covered by each interval (layers start..end inclusive)."""
+        lay_slices = {}
+        for layer_idx, layer in enumerate(self._model.layers):
+            if layer._dense_index is not None:
+                lay_slices[layer_idx] = self._model.spec.layer_slices()[layer._dense_index]
+        out = []
+        for start, end in self._layers_dtbn_intervals:
+            idxs = [i for i in range(start, end + 1) if i in lay_slices]
+            if idxs:
+                out.append(slice(lay_slices[idxs[0]].start, lay_slices[idxs[-1]].stop))
+            else:
+                out.append(slice(0, 0))
+        return out
+
+    def sample_weights_matrix(self, n: int) -> np.ndarray:
+        """(n, D) float32: n joint draws, one ``Distribution`` draw per interval (BayesianModel.py:63-77)."""
+        W = np.repeat(self._model.weights_flat[None, :], n, axis=0).astype(np.float32)
+        for dist, sl in zip(self._distributions, self._interval_slices()):
+            if sl.stop > sl.start:
+                draws = np.asarray(dist.sample_n(n), dtype=np.float32)
+                W[:, sl] = draws[:, : sl.stop - sl.start]
+        return W
+
+    def _sample_weights(self):
+        self._model.set_flat(self.sample_weights_matrix(1)[0])
+
+    def sample_model(self) -> DenseNet:
+        self._sample_weights()
+        model = model_from_json(self._model_config)
+        model.set_flat(self._model.weights_flat)
+        return model
+
+    def sample_n_models(self, n) -> list:
+        return [self.sample_model() for _ in range(n)]
+
+    # ------------------------------------------------------------------ read-out
+    def predict(self, x, nb_samples: int, y_true=None, loss_func=None):
+        """(list of per-sample outputs, their mean); NaN outputs count as 0 (BayesianModel.py:106-129)."""
+        import torch
+        from ..engine import MLPPlan
+        x = np.asarray(x.numpy() if hasattr(x, "numpy") else x)
+        x = np.ascontiguousarray(x.astype(np.float32).reshape(len(x), -1))
+        nb_samples = int(nb_samples)
+        W = self.sample_weights_matrix(nb_samples)
+        n = len(x)
+        # bound the activation workspace: rows x samples per launch
+        rows = min(n, 8192)
+        chunk_s = max(1, min(nb_samples, (1 << 24) // max(1, rows * max(self._model.dims))))
+        if self._plan is None or self._plan.max_batch < rows or self._plan.max_particles < chunk_s:
+            self._plan = MLPPlan(self._model.spec, max_batch=rows, max_particles=chunk_s)
+        Wd = torch.as_tensor(W).cuda()
+        xd = torch.as_tensor(x).cuda()
+        outs, means = [], []
+        for r0 in range(0, n, rows):
+            samples, mean = self._plan.predict(Wd, xd[r0:r0 + rows].contiguous())
+            outs.append(samples.cpu().numpy())
+            means.append(mean.cpu().numpy())
+        samples = np.concatenate(outs, axis=1)
+        mean = np.concatenate(means, axis=0)
+        self._model.set_flat(W[-1])                     # the reference leaves the last draw assigned
+        return [Array(s) for s in samples], Array(mean)
+
+    # ------------------------------------------------------------------ persistence
+    @classmethod
+    def load(cls, model_path: str, custom_distribution_register=None) -> "BayesianModel":
+        from ..distributions import Sampled
+        from ..distributions.tf import TensorflowProbabilityDistribution
+        register = {"Sampled": Sampled, "TensorflowProbabilityDistribution": TensorflowProbabilityDistribution}
+        register.update(custom_distribution_register or {})
+        with open(os.path.join(model_path, "config.json"), "r") as f:
+            bayesian_model = BayesianModel(f.read())
+        layers_intervals = []
+        with open(os.path.join(model_path, "layers_config.txt"), "r") as f:
+            n_intervals = int(f.readline())
+            for _ in range(n_intervals):
+                layers_intervals.append((f.readline()[:-1], int(f.readline()), int(f.readline())))
+        for i, (name, start, end) in enumerate(layers_intervals):
+            dist = register[name].load(os.path.join(model_path, "distribution" + str(i)))
+            bayesian_model.apply_distribution(dist, start, end)
+        return bayesian_model
+
+    def _empty_folder(self, path):
+        for filename in os.listdir(path):
+            file_path = os.path.join(path, filename)
+            try:
+                if os.path.isfile(file_path) or os.path.islink(file_path):
+                    os.unlink(file_path)
+                elif os.path.isdir(file_path):
+                    shutil.rmtree(file_path)
+            except Exception as e:
+                print('Failed to delete %s. Reason: %s' % (file_path, e))
+
+    def store(self, model_path: str):
+        """Directory format of BayesianModel.py:177-203: config.json, layers_config.txt
+        (count, then ClassName / start / end per interval), distribution<i>/."""
+        if not os.path.exists(model_path):
+            os.makedirs(model_path)
+        self._empty_folder(model_path)
+        with open(os.path.join(model_path, "config.json"), "w") as f:
+            f.write(self._model.to_json())
+        with open(os.path.join(model_path, "layers_config.txt"), "w") as f:
+            f.write(str(len(self._layers_dtbn_intervals)) + '\n')
+            for (start, end), d in zip(self._layers_dtbn_intervals, self._distributions):
+                f.write(d.__class__.__name__ + '\n' + str(start) + '\n' + str(end) + '\n')
+        for i, d in enumerate(self._distributions):
+            os.mkdir(os.path.join(model_path, "distribution" + str(i)))
+            d.store(os.path.join(model_path, "distribution" + str(i)))

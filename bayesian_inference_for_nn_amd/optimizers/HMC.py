@@ -1,0 +1,116 @@
+"""Hamiltonian Monte Carlo on the full training split (mirrors Pyesian/optimizers/HMC.py:13-187).
+Hyperparameters: m, L, epsilon; kwarg prior (GaussianPrior).  Extension: kwarg n_chains runs
+that many independent chains in one particle-batched launch (the reference has one)."""
+
+import random
+
+import numpy as np
+
+from ..distributions import Sampled
+from ..nn import BayesianModel
+from .Optimizer import DeviceScalar, Optimizer
+
+
+class HMC(Optimizer):
+    def __init__(self):
+        super().__init__()
+        self._nb_burn_epoch = 10
+        self._prior = None
+        self._frequency = None
+        self._samples = None
+        self._epsilon = None
+        self._L = None
+        self._m = None
+        self._total_runs = 0
+        self._accepted_runs = 0
+        self._current_loss = 0
+
+    def compile_extra_components(self, **kwargs):
+        import torch
+        self._m = self._hyperparameters.m
+        self._L = self._hyperparameters.L
+        self._epsilon = self._hyperparameters.epsilon
+        self._n_chains = int(kwargs.get("n_chains", 1))
+        self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_chains, full_batch=True)
+        self._model = self._net
+        self._samples = []
+        self._frequency = []
+        self._prior_spec = kwargs["prior"]
+        self._prior = self._prior_spec.get_model_priors(self._net)
+        if "nb_burn_epoch" in kwargs:
+            # the reference tests one key and reads another (HMC.py:61-62); kept as written
+            self._nb_burn_epoch = kwargs["nb_burn_epochs"]
+        if not self._prior_spec.is_scalar():
+            raise NotImplementedError("HMC kernels take a scalar GaussianPrior (mean, rho)")
+        self._prior_mean, self._prior_sigma = float(self._prior_spec._mean), float(self._prior_spec._std_dev)
+        self._dataset_setup()
+        # q <- prior mean (HMC.py:69-72)
+        mu, _ = self._prior_spec.flat(self._net)
+        self._q = torch.as_tensor(np.repeat(mu[None, :], self._n_chains, axis=0).copy()).cuda()
+        self._stats = torch.zeros((self._n_chains, 8), device="cuda")
+        self._step_count = 0
+        self._chain_samples = [[] for _ in range(self._n_chains)]
+        self._chain_freq = [[] for _ in range(self._n_chains)]
+
+    def step(self, save_document_path=None, sampling=True, burning=False):
+        if sampling:
+            for c in range(self._n_chains):                    # HMC.py:75-77: records the starting q
+                if len(self._chain_freq[c]) == 0:
+                    self._chain_freq[c].append(1)
+                    self._chain_samples[c].append(self._q[c].clone())
+        uniforms = [random.random() for _ in range(self._n_chains)]      # HMC.py:91 host Mersenne Twister
+        self._plan.hmc_step(self._q, self._x_dev, self._y_dev, int(self._L), self._epsilon, self._m, self._prior_mean,
+                            self._prior_sigma, uniforms, self._step_count, self._seed, self._stats, burning=burning)
+        self._step_count += 1
+        stats = self._stats.cpu().numpy()
+        self._total_runs += 1
+        accepted = stats[:, 0] != 0
+        if accepted[0]:
+            self._accepted_runs += 1
+        if sampling:
+            for c in range(self._n_chains):
+                if accepted[c]:                                 # HMC.py:92-96
+                    self._chain_freq[c].append(1)
+                    self._chain_samples[c].append(self._q[c].clone())
+                else:                                           # HMC.py:102-103
+                    self._chain_freq[c][-1] += 1
+        self._frequency, self._samples = self._chain_freq[0], self._chain_samples[0]
+        self.last_stats = stats
+        return DeviceScalar(self._stats.clone(), 1)
+
+    def train(self, nb_iterations: int, loss_save_document_path: str = None, model_save_frequency: int = None,
+              model_save_path: str = None):
+        self._accepted_runs = 0
+        self._total_runs = 0
+        nb_burn_epoch = self._nb_burn_epoch
+        for i in range(nb_burn_epoch):                          # HMC.py:111-116
+            loss = self.step(sampling=False, burning=True)
+            accept_rate = self._accepted_runs / self._total_runs
+            self._print_progress((i + 1) / nb_burn_epoch, suffix="HMC - Burning", loss=loss.numpy().item(),
+                                 accept_rate=accept_rate, bar_length=20)
+        self._new_progress_line()
+        self._accepted_runs = 0
+        self._total_runs = 0
+        self._chain_freq = [[] for _ in range(self._n_chains)]
+        self._chain_samples = [[] for _ in range(self._n_chains)]
+        for i in range(nb_iterations):                          # HMC.py:121-125
+            loss = self.step(sampling=True, burning=False)
+            accept_rate = self._accepted_runs / self._total_runs
+            self._print_progress((i + 1) / nb_iterations, suffix="HMC - Sampling", loss=loss.numpy().item(),
+                                 accept_rate=accept_rate, bar_length=20)
+        self._new_progress_line()
+
+    def update_parameters_step(self):
+        pass
+
+    def result(self) -> BayesianModel:
+        """Sampled(samples, frequencies) over all layers (HMC.py:176-187); with n_chains > 1 the chains'
+        samples and frequencies are concatenated (independent chains of the same posterior)."""
+        samples, freqs = [], []
+        for c in range(self._n_chains):
+            samples += [s.cpu().numpy() for s in self._chain_samples[c]]
+            freqs += list(self._chain_freq[c])
+        distribution = Sampled(samples, freqs)
+        posterior_model = BayesianModel(self._model_config)
+        posterior_model.apply_distribution(distribution, 0, len(self._net.layers) - 1)
+        return posterior_model

@@ -1,0 +1,219 @@
+"""Abstract base of the inference methods (mirrors Pyesian/optimizers/Optimizer.py:14-165:
+compile-once guard, shuffled/batched training iterator, ``train`` loop with progress bar,
+optional loss file and periodic ``result().store``).  The data set is uploaded to HBM once at
+compile time; a batch is a slice of a per-epoch device permutation, gathered inside the kernels."""
+
+from __future__ import annotations
+
+import math
+import os
+import shutil
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from ..losses import loss_kind
+from ..nn.model import Array
+
+
+class DeviceScalar:
+    """A loss that stays on the device until somebody looks at it (``Optimizer.train`` prints the
+    loss every step when verbose: Optimizer.py:123 -- formatting is what triggers the sync)."""
+
+    def __init__(self, tensor, index=0, scale=1.0):
+        self._t, self._i, self._s = tensor, index, scale
+
+    def __float__(self):
+        return float(self._t.reshape(-1)[self._i].item()) * self._s
+
+    def item(self):
+        return float(self)
+
+    def numpy(self):
+        return Array(np.float32(float(self)))
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    __str__ = __repr__
+
+
+class Optimizer(ABC):
+    def __init__(self):
+        self._model_config = None
+        self._hyperparameters = None
+        self.__compiled = False
+        self._dataset = None
+
+    # ------------------------------------------------------------------ reference surface
+    @abstractmethod
+    def step(self, save_document_path=None):
+        pass
+
+    def compile(self, hyperparameters, model_config: str, dataset, verbose=True, **kwargs):
+        if self.__compiled:
+            raise Exception("Model Already compiled")
+        else:
+            self.__compiled = True
+            self._hyperparameters = hyperparameters
+            self._model_config = model_config
+            self._dataset = dataset
+            self._verbose = verbose
+        self.compile_extra_components(**kwargs)
+
+    @abstractmethod
+    def compile_extra_components(self, **kwargs):
+        pass
+
+    @abstractmethod
+    def update_parameters_step(self):
+        pass
+
+    @abstractmethod
+    def result(self):
+        pass
+
+    def _empty_folder(self, path):
+        for filename in os.listdir(path):
+            file_path = os.path.join(path, filename)
+            try:
+                if os.path.isfile(file_path) or os.path.islink(file_path):
+                    os.unlink(file_path)
+                elif os.path.isdir(file_path):
+                    shutil.rmtree(file_path)
+            except Exception as e:
+                print('Failed to delete %s. Reason: %s' % (file_path, e))
+
+    def train_with_weights_and_biases(self, nb_iterations, project_name, weights_and_biases_config):
+        raise RuntimeError("wandb is not available in this environment (no network)")
+
+    def train(self, nb_iterations: int, loss_save_document_path: str = None, model_save_frequency: int = None,
+              model_save_path: str = None, weights_and_biases_log=False):
+        if model_save_frequency == None and model_save_path != None:
+            raise Exception("Error: save path precised and save frequency is None, please provide a savong frequency")
+        if model_save_frequency != None and model_save_path == None:
+            raise Exception("Error: save frequency precised and save path is None, please provide a saving path")
+        if weights_and_biases_log:
+            raise RuntimeError("wandb is not available in this environment (no network)")
+        if loss_save_document_path != None and os.path.exists(loss_save_document_path):
+            os.remove(loss_save_document_path)
+        if model_save_path != None:
+            self._empty_folder(model_save_path)
+
+        quiet = (not self._verbose and loss_save_document_path is None and model_save_frequency is None)
+        if quiet and self._train_resident(nb_iterations):
+            return
+        saved_model_nbr = 0
+        for i in range(nb_iterations):
+            loss = self.step(loss_save_document_path)
+            self._print_progress(i / nb_iterations, loss=loss)
+            if model_save_frequency != None and i % model_save_frequency == 0:
+                bayesian_model = self.result()
+                target = os.path.join(model_save_path, "model" + str(saved_model_nbr))
+                if os.path.exists(target):
+                    shutil.rmtree(target)
+                os.makedirs(target)
+                (bayesian_model[0] if isinstance(bayesian_model, tuple) else bayesian_model).store(target)
+                saved_model_nbr += 1
+        if self._verbose:
+            print()
+
+    def _train_resident(self, nb_iterations: int) -> bool:
+        """Hook: run all iterations without per-step host work (returns False if unsupported)."""
+        return False
+
+    def _print_progress(self, progress: float, bar_length=10, suffix="Training", **kwargs):
+        if not self._verbose:
+            return
+        nb_chars = math.ceil(progress * bar_length)
+        bar = "[" + nb_chars * "="
+        if nb_chars < bar_length:
+            bar += ">"
+        bar += "]"
+        infos = ' '.join("{}: {}".format(k, v) for k, v in kwargs.items())
+        percentage = str(math.ceil(progress * 100))
+        print("\r" + suffix + " " + percentage + " % " + bar + " " + infos, end="")
+
+    def _new_progress_line(self):
+        if not self._verbose:
+            return
+        print()
+
+    # ------------------------------------------------------------------ device-resident data
+    def _setup_backend(self, seed=None, max_particles=1, full_batch=False):
+        """Builds the model, the kernel plan and the device copy of the training split."""
+        import torch
+        from ..engine import MLPPlan, MLPSpec
+        from ..nn.model import model_from_json
+        self._seed = int(seed) if seed is not None else int.from_bytes(os.urandom(6), "little")
+        self._rng = np.random.default_rng(self._seed)
+        self._net = model_from_json(self._model_config)
+        self._net.reset_glorot(self._rng)
+        self._loss_kind = loss_kind(self._dataset._loss)
+        self._spec = MLPSpec(self._net.dims, self._net.acts, self._loss_kind)
+        x, y = self._dataset.training_dataset().as_numpy()
+        self._training_dataset_cardinality = len(x)
+        self._x_dev = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(len(x), -1))).cuda()
+        self._y_dev = self._labels_to_device(y)
+        if full_batch:
+            self._batch_size = len(x)
+        self._plan = MLPPlan(self._spec, max_batch=max(1, min(int(self._batch_size), len(x))),
+                             max_particles=max_particles)
+        self._D = self._plan.D
+
+    def _labels_to_device(self, y):
+        import torch
+        y = np.asarray(y)
+        if self._loss_kind == "scce":
+            return torch.as_tensor(np.ascontiguousarray(y.reshape(-1).astype(np.int32))).cuda()
+        return torch.as_tensor(np.ascontiguousarray(y.astype(np.float32).reshape(len(y), -1))).cuda()
+
+    def _dataset_setup(self):
+        """shuffle(cardinality).batch(batch_size) + iter (Optimizer.py:35-41): a device permutation
+        per epoch, ragged last batch, fresh permutation when exhausted."""
+        self._training_dataset = self._dataset.training_dataset()
+        self._perm_dev = None
+        self._pos = 0
+        self._epoch = -1
+
+    def _new_epoch(self):
+        import torch
+        self._epoch += 1
+        perm = self._rng.permutation(self._training_dataset_cardinality).astype(np.int32)
+        self._perm_dev = torch.as_tensor(perm).cuda()
+        self._pos = 0
+
+    def _next_batch(self):
+        """(row-index view on the device, batch size, True when a new epoch started)."""
+        new_epoch = False
+        if self._perm_dev is None or self._pos >= self._training_dataset_cardinality:
+            new_epoch = self._perm_dev is not None
+            self._new_epoch()
+        b = min(int(self._batch_size), self._training_dataset_cardinality - self._pos)
+        idx = self._perm_dev[self._pos:self._pos + b]
+        self._pos += b
+        return idx, b, new_epoch
+
+    def _batch_plan(self, n_steps: int):
+        """Row indices of the next n_steps batches as one (n_steps, max_batch) table + sizes."""
+        import torch
+        B = self._plan.max_batch
+        table = np.zeros((n_steps, B), dtype=np.int32)
+        sizes = []
+        host_perm = None if self._perm_dev is None else self._perm_dev.cpu().numpy()
+        for s in range(n_steps):
+            if host_perm is None or self._pos >= self._training_dataset_cardinality:
+                self._new_epoch()
+                host_perm = self._perm_dev.cpu().numpy()
+            b = min(int(self._batch_size), self._training_dataset_cardinality - self._pos)
+            table[s, :b] = host_perm[self._pos:self._pos + b]
+            self._pos += b
+            sizes.append(b)
+        return torch.as_tensor(table).cuda(), sizes
+
+    def _layer_indices(self):
+        """indices (in model.layers) of the layers that own parameters"""
+        return [i for i, l in enumerate(self._net.layers) if len(l.trainable_variables) != 0]

@@ -1,0 +1,133 @@
+"""Stein variational gradient descent over M particles (mirrors Pyesian/optimizers/SVGD.py:45-251).
+Hyperparameters: lr, M, batch_size; kwarg prior.  All M loss gradients come from one
+particle-batched pass; the sequential (Gauss-Seidel) particle sweep, the float64 RBF kernel row,
+the repulsion term and the per-particle legacy Adam run on the device.
+Multi-GPU: under torch.distributed the particles are sharded by rank and every step all-gathers
+the particle matrix over RCCL (Jacobi sweep)."""
+
+import numpy as np
+
+from ..nn.model import model_from_json
+from .BBB import ResultTuple
+from .Optimizer import DeviceScalar, Optimizer
+
+
+class Ensemble(list):
+    """``SVGD.result()[0]``: the list of particle models, with the ensemble-mean predict."""
+
+    def predict(self, x, *a, **k):
+        out = None
+        for m in self:
+            p = m.predict(x)
+            out = p if out is None else out + p
+        return out / len(self)
+
+
+class SVGD(Optimizer):
+    def __init__(self):
+        super().__init__()
+        self._step = 0
+        self._M = None
+        self._particles = None
+        self.train_losses = []
+        self.valid_losses = []
+
+    def compile_extra_components(self, **kwargs):
+        import torch
+        from .. import _lib
+        from ..engine import MLPPlan, fill_normal
+        self._batch_size = int(self._hyperparameters.batch_size)
+        self._prior = kwargs["prior"]
+        self._M = int(self._hyperparameters.M)
+        self._lr = self._hyperparameters.lr
+        self._gamma = float(kwargs.get("gamma", 1.0))           # SVGD.py:183: gamma = 1 fixed in the reference
+        # particle sharding over ranks (one process per GPU); single process = the reference's sweep
+        self._world, self._rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and kwargs.get("shard", True):
+                self._world, self._rank = dist.get_world_size(), dist.get_rank()
+        except Exception:
+            pass
+        if self._M % self._world != 0:
+            raise ValueError("the particle count M must be a multiple of the number of ranks")
+        self._n_local = self._M // self._world
+        self._row0 = self._rank * self._n_local
+        self._sweep = kwargs.get("sweep", "gauss_seidel" if self._world == 1 else "jacobi")
+        if self._world > 1 and self._sweep != "jacobi":
+            raise ValueError("sharded particles need the Jacobi sweep")
+        self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local)
+        self._base_model = self._net
+        self._dataset_setup()
+        self._num_particles = self._D
+        # _init_particles (SVGD.py:143-157): row i = prior samples, drawn here on the device
+        mu, rho = self._prior.flat(self._net)
+        all_p = torch.empty((self._M, self._D), device="cuda")
+        fill_normal(all_p, self._seed, _lib.STREAM_INIT, 0, 0.0, 1.0)
+        all_p = all_p * torch.as_tensor(rho).cuda() + torch.as_tensor(mu).cuda()
+        self._all = all_p.contiguous()
+        if self._world == 1:
+            self._local = self._all                             # same storage: the sweep updates it in place
+        else:
+            self._local = self._all[self._row0:self._row0 + self._n_local].clone()
+        self._adam_m = torch.zeros((self._n_local, self._D), device="cuda")
+        self._adam_v = torch.zeros((self._n_local, self._D), device="cuda")
+        self._loss_dev = torch.zeros(1, device="cuda")
+        vx, vy = self._dataset.valid_data.as_numpy()
+        self._val_n = len(vx)
+        if self._val_n > 0:
+            self._vx = torch.as_tensor(np.ascontiguousarray(np.asarray(vx, np.float32).reshape(len(vx), -1))).cuda()
+            self._vy = self._labels_to_device(vy)
+            self._val_plan = MLPPlan(self._spec, max_batch=self._val_n, max_particles=self._n_local)
+
+    @property
+    def _particles_host(self):
+        return self._all.cpu().numpy().astype(np.float64)
+
+    def step(self, save_document_path=None):
+        import torch
+        self._step += 1
+        idx, b, _ = self._next_batch()
+        if self._world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self._all, self._local)         # the one exchange step of the path
+            snapshot = self._all
+        elif self._sweep == "jacobi":
+            snapshot = self._all.clone()
+        else:
+            snapshot = self._all
+        self._plan.svgd_step(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._x_dev, self._y_dev,
+                             self._lr, self._gamma, self._step, self._loss_dev, sweep=self._sweep, batch=b, row_idx=idx)
+        total_loss = self._loss_dev.clone()
+        if self._world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(total_loss)
+        loss = DeviceScalar(total_loss, 0)
+        if self._val_n > 0:                                     # SVGD.py:126-129: validation forward per particle
+            vl, _ = self._val_plan.loss_grad(self._local, self._vx, self._vy, want_grad=False)
+            total_val = vl.sum() / self._M
+            if self._world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(total_val)
+        else:
+            total_val = torch.zeros((), device="cuda")
+        if self._step % 10 == 0:                                # SVGD.py:137-139
+            self.train_losses.append(loss)
+            self.valid_losses.append(DeviceScalar(total_val.reshape(1), 0))
+        return loss
+
+    def update_parameters_step(self):
+        pass
+
+    def result(self):
+        import torch
+        if self._world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self._all, self._local)
+        P = self._all.cpu().numpy()
+        ensemble = Ensemble()
+        for i in range(self._M):                                # SVGD.py:244-249
+            m = model_from_json(self._model_config)
+            m.set_flat(P[i])
+            ensemble.append(m)
+        return ResultTuple((ensemble, self.train_losses, self.valid_losses))

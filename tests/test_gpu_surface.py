@@ -1,0 +1,207 @@
+"""End-to-end tests of the drop-in Python surface on the GPU: the reference's call pattern
+(compile / train / step / result / predict) driven through the HIP kernels, checked against
+the CPU oracle where a deterministic comparison exists."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import mlp as o_mlp
+from oracle import philox as o_philox
+from oracle import predict as o_predict
+from oracle import sgld as o_sgld
+from oracle import bbb as o_bbb
+
+from bayesian_inference_for_nn_amd import synth
+from bayesian_inference_for_nn_amd.datasets import Dataset
+from bayesian_inference_for_nn_amd.distributions import GaussianPrior
+from bayesian_inference_for_nn_amd.losses import MeanSquaredError, SparseCategoricalCrossentropy
+from bayesian_inference_for_nn_amd.nn import BayesianModel, model_from_json, sequential_json
+from bayesian_inference_for_nn_amd.optimizers import BBB, HMC, SGD, SGLD, SVGD
+from bayesian_inference_for_nn_amd.optimizers.hyperparameters import HyperParameters
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(gpu_device):
+    return gpu_device
+
+
+def moons_dataset(n=500, seed=3):
+    x, y = synth.moons(n, seed=42)
+    return Dataset((x, y), SparseCategoricalCrossentropy, "Classification", seed=seed)
+
+
+MOONS_JSON = sequential_json(2, [16, 2], ["relu", "softmax"])
+
+
+def test_sgd_regression_example_converges():
+    """simple_regression_example.py: y = 2x + 2, Dense(1), SGD(lr=1e-3, frequency=1)."""
+    x, y = synth.linreg(600)
+    ds = Dataset((x, y), MeanSquaredError, "Regression", seed=0)
+    cfg = sequential_json(1, [1], ["linear"])
+    start = model_from_json(cfg)
+    start.set_weights([np.array([[0.3]]), np.array([-0.1])])
+    opt = SGD()
+    opt.compile(HyperParameters(lr=1e-3, frequency=1), cfg, ds, verbose=False, starting_model=start, seed=1)
+    first = float(opt.step())
+    opt.train(3000)
+    bm = opt.result()
+    assert isinstance(bm, BayesianModel)
+    w, b = bm._model.layers[0].trainable_variables
+    assert abs(w[0, 0] - 2.0) < 0.1 and abs(float(opt.step())) < first / 50
+    xt, yt = next(iter(ds.test_data.batch(ds.test_size)))
+    samples, mean = bm.predict(xt, nb_samples=3)
+    assert len(samples) == 3 and mean.shape == (ds.test_size, 1)
+    np.testing.assert_allclose(mean, xt.numpy() * w[0, 0] + b[0], rtol=1e-5, atol=1e-4)     # Deterministic posterior
+    with pytest.raises(Exception, match="Model Already compiled"):
+        opt.compile(HyperParameters(lr=1e-3, frequency=1), cfg, ds, starting_model=start)
+
+
+def test_sgld_surface_matches_oracle_and_resident_training():
+    ds = moons_dataset()
+    hyp = HyperParameters(lr_upper=0.01, lr_lower=0.003, lr_gamma=0.99, batch_size=96)
+    n_steps = 11                                      # 400 train rows / 96 -> ragged batch of 16 every 5th step
+    opt = SGLD()
+    opt.compile(hyp, MOONS_JSON, ds, verbose=False, seed=123)
+    theta0 = opt._theta.cpu().numpy().copy()
+    # oracle replay of the same batches and the same Philox noise stream
+    spec = o_mlp.MLPSpec((2, 16, 2), ("relu", "softmax"), "scce")
+    x, y = ds.train_data.as_numpy()
+    st = o_sgld.SGLDState(theta0)
+    lr = o_sgld.lr_schedule(n_steps, 0.01, 0.003, 0.99)
+    opt._nb_iterations = n_steps
+    opt._init_sgld_lr()
+    rets = []
+    for s in range(n_steps):
+        ret = opt.step()
+        pos, b = opt._pos, None
+        perm = opt._perm_dev.cpu().numpy()
+        rows = perm[pos - (96 if pos % 96 == 0 else pos % 96):pos]
+        _, r = o_sgld.sgld_step(st, x[rows], y[rows], spec, lr(s), o_philox.normal(opt._seed, 0, s, spec.n_params))
+        rets.append((float(ret), r))
+    for got, ref in rets:
+        assert abs(got - ref) <= 1e-4 * abs(ref)
+    np.testing.assert_allclose(opt._theta.cpu().numpy(), st.theta, rtol=0, atol=1e-4 * np.abs(st.theta).max())
+    bm = opt.result()
+    np.testing.assert_allclose(bm._distributions[0]._tf_distribution.loc, st.mean[:48], atol=1e-5)
+    np.testing.assert_allclose(bm._distributions[1]._tf_distribution.scale, (st.sq_mean - st.mean ** 2)[48:], atol=1e-6)
+    # verbose=False training runs device-resident (hipGraph) and must agree with the stepwise path
+    a, b2 = SGLD(), SGLD()
+    a.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
+    b2.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
+    a.train(70)
+    b2._nb_iterations = 70
+    b2._init_sgld_lr()
+    for _ in range(70):
+        b2.step()
+    ta, tb = a._theta.cpu().numpy(), b2._theta.cpu().numpy()
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-5 * np.abs(tb).max())
+    assert a._n == 70 and abs(float(a._running_dev.item()) - float(b2._running_dev.item())) < 1e-3
+
+
+def test_hmc_surface_bookkeeping_and_nan_prior():
+    import random
+    random.seed(0)
+    ds = moons_dataset()
+    opt = HMC()
+    opt.compile(HyperParameters(epsilon=0.002, m=0.5, L=8), MOONS_JSON, ds, verbose=False, prior=GaussianPrior(0.0, 1.0), seed=5)
+    assert opt._batch_size == 400 and float(opt._q.abs().max()) == 0.0          # q <- prior mean
+    opt.train(12)
+    assert sum(opt._frequency) == 13 and len(opt._samples) == len(opt._frequency)   # starting q + 12 proposals
+    assert opt._total_runs == 12 and 0 < opt._accepted_runs <= 12
+    bm = opt.result()
+    assert bm._layers_dtbn_intervals == [[0, 1]]
+    xt, yt = next(iter(ds.test_data.batch(ds.test_size)))
+    _, mean = bm.predict(xt, nb_samples=20)
+    np.testing.assert_allclose(mean.sum(axis=1), 1.0, atol=1e-5)
+    # negative rho (HMC_classification.py:50): NaN potential -> every non-burn proposal rejected
+    opt2 = HMC()
+    opt2.compile(HyperParameters(epsilon=0.005, m=0.5, L=3), MOONS_JSON, ds, verbose=False, prior=GaussianPrior(0.0, -1.0), seed=5)
+    opt2.train(6)
+    assert opt2._accepted_runs == 0 and opt2._frequency == [7] and len(opt2._samples) == 1
+    # the kwarg-name quirk of HMC.py:61-62 is reproduced
+    with pytest.raises(KeyError):
+        HMC().compile(HyperParameters(epsilon=0.005, m=0.5, L=3), MOONS_JSON, ds, verbose=False,
+                      prior=GaussianPrior(0.0, 1.0), nb_burn_epoch=3)
+    # independent chains in one launch
+    opt3 = HMC()
+    opt3.compile(HyperParameters(epsilon=0.005, m=0.5, L=4), MOONS_JSON, ds, verbose=False, prior=GaussianPrior(0.0, 1.0),
+                 seed=5, n_chains=3)
+    opt3.train(4)
+    assert all(sum(f) == 5 for f in opt3._chain_freq)
+    assert not torch.equal(opt3._q[0], opt3._q[1])
+
+
+def test_bbb_surface_matches_oracle_and_result_tuple():
+    ds = moons_dataset()
+    opt = BBB()
+    opt.compile(HyperParameters(lr=0.05, alpha=0.1, batch_size=128, pi=0.75), MOONS_JSON, ds, verbose=False,
+                prior=GaussianPrior(0.0, -1.0), prior2=GaussianPrior(0.5, 0.5), seed=9)
+    pm, pr = o_bbb.mix_prior(0.0, -1.0, 0.5, 0.5, 0.75)
+    assert abs(opt._prior._mean - pm) < 1e-12 and abs(opt._prior._std_dev - pr) < 1e-12
+    spec = o_mlp.MLPSpec((2, 16, 2), ("relu", "softmax"), "scce")
+    x, y = ds.train_data.as_numpy()
+    mu, rho = opt._mu.cpu().numpy().astype(np.float64), opt._rho.cpu().numpy().astype(np.float64)
+    assert np.all(mu == pm) and np.allclose(rho, pr)
+    for s in range(1, 13):
+        cost = opt.step()
+        pos = opt._pos
+        perm = opt._perm_dev.cpu().numpy()
+        rows = perm[pos - (128 if pos % 128 == 0 else pos % 128):pos]
+        out = o_bbb.bbb_step(mu, rho, o_philox.normal(opt._seed, 1, s, spec.n_params), x[rows], y[rows], spec, 0.05, 0.1, pm, pr)
+        mu, rho = out["mu"], out["rho"]
+        assert abs(float(cost) - out["cost"]) <= 1e-4 * abs(out["cost"]) + 1e-5
+    np.testing.assert_allclose(opt._mu.cpu().numpy(), mu, atol=1e-4 * np.abs(mu).max())
+    np.testing.assert_allclose(opt._rho.cpu().numpy(), rho, atol=1e-4 * np.abs(rho).max())
+    assert len(opt.train_losses) == 11 and len(opt.val_losses) == 11          # every step except step 10 (BBB.py:203)
+    vx, vy = ds.valid_data.as_numpy()
+    ref_val = o_bbb.validation_loss(opt._w.cpu().numpy(), vx, vy, spec)
+    assert abs(float(opt.val_losses[-1]) - ref_val) <= 1e-4 * ref_val
+    res = opt.result()
+    model, tl, vl = res
+    assert isinstance(model, BayesianModel) and tl is opt.train_losses and vl is opt.val_losses
+    xt, _ = next(iter(ds.test_data.batch(ds.test_size)))
+    _, mean = res.predict(xt, nb_samples=8)             # attribute access forwards to the model (BBB_mnist.py:59)
+    assert mean.shape == (ds.test_size, 2)
+    np.testing.assert_allclose(model._distributions[1]._tf_distribution.scale, o_bbb.softplus(rho)[48:], rtol=1e-4)
+
+
+def test_svgd_surface():
+    ds = moons_dataset()
+    opt = SVGD()
+    opt.compile(HyperParameters(lr=0.05, M=4, batch_size=100), MOONS_JSON, ds, verbose=False, prior=GaussianPrior(0.0, 1.0), seed=2)
+    assert opt._all.shape == (4, 82) and opt._sweep == "gauss_seidel"
+    p0 = opt._all.clone()
+    assert abs(float(p0.std()) - 1.0) < 0.2
+    losses = [float(opt.step()) for _ in range(20)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert len(opt.train_losses) == 2 and len(opt.valid_losses) == 2          # every 10 steps (SVGD.py:137-139)
+    assert not torch.equal(p0, opt._all)
+    ensemble, tl, vl = opt.result()
+    assert len(ensemble) == 4
+    xt, yt = next(iter(ds.test_data.batch(ds.test_size)))
+    agg = sum(m.predict(xt) for m in ensemble) / len(ensemble)
+    np.testing.assert_allclose(agg, ensemble.predict(xt), rtol=1e-6)
+    np.testing.assert_allclose(ensemble[1].get_weights()[0].reshape(-1), opt._all[1, :32].cpu().numpy())
+
+
+def test_bayesian_model_predict_matches_oracle():
+    cfg = sequential_json((4, 4), [12, 3], ["tanh", "softmax"])
+    bm = BayesianModel(cfg)
+    from bayesian_inference_for_nn_amd.distributions import Sampled
+    rng = np.random.default_rng(0)
+    D = bm._model.count_params()
+    cand = [(rng.normal(size=D) * 0.4).astype(np.float32) for _ in range(5)]
+    bm.apply_distribution(Sampled(cand, [1, 2, 3, 1, 1]), 0, 2)
+    x = rng.normal(size=(37, 4, 4)).astype(np.float32)
+    W = bm.sample_weights_matrix(6)
+    bm.sample_weights_matrix = lambda n: W[:n]
+    samples, mean = bm.predict(x, nb_samples=6)
+    spec = o_mlp.MLPSpec((16, 12, 3), ("tanh", "softmax"), "scce")
+    rs, rm = o_predict.predict(W, x.reshape(37, -1), spec)
+    np.testing.assert_allclose(np.stack(samples), rs, atol=1e-5)
+    np.testing.assert_allclose(mean, rm, atol=1e-5)
+    assert np.array_equal(np.argmax(mean, axis=1), np.argmax(rm, axis=1))          # integer class labels bit-exact
