@@ -42,17 +42,9 @@ class SVGD(Optimizer):
         self._lr = self._hyperparameters.lr
         self._gamma = float(kwargs.get("gamma", 1.0))           # SVGD.py:183: gamma = 1 fixed in the reference
         # particle sharding over ranks (one process per GPU); single process = the reference's sweep
-        self._world, self._rank = 1, 0
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and kwargs.get("shard", True):
-                self._world, self._rank = dist.get_world_size(), dist.get_rank()
-        except Exception:
-            pass
-        if self._M % self._world != 0:
-            raise ValueError("the particle count M must be a multiple of the number of ranks")
-        self._n_local = self._M // self._world
-        self._row0 = self._rank * self._n_local
+        from .. import parallel
+        self._rank, self._world = parallel.world_info() if kwargs.get("shard", True) else (0, 1)
+        self._row0, self._n_local = parallel.shard_range(self._M, self._world, self._rank)
         self._sweep = kwargs.get("sweep", "gauss_seidel" if self._world == 1 else "jacobi")
         if self._world > 1 and self._sweep != "jacobi":
             raise ValueError("sharded particles need the Jacobi sweep")
@@ -88,9 +80,9 @@ class SVGD(Optimizer):
         import torch
         self._step += 1
         idx, b, _ = self._next_batch()
+        from .. import parallel
         if self._world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self._all, self._local)         # the one exchange step of the path
+            parallel.all_gather_rows(self._local, self._all)            # the one exchange step of the path
             snapshot = self._all
         elif self._sweep == "jacobi":
             snapshot = self._all.clone()
@@ -98,17 +90,11 @@ class SVGD(Optimizer):
             snapshot = self._all
         self._plan.svgd_step(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._x_dev, self._y_dev,
                              self._lr, self._gamma, self._step, self._loss_dev, sweep=self._sweep, batch=b, row_idx=idx)
-        total_loss = self._loss_dev.clone()
-        if self._world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(total_loss)
+        total_loss = parallel.sum_over_ranks(self._loss_dev.clone())
         loss = DeviceScalar(total_loss, 0)
         if self._val_n > 0:                                     # SVGD.py:126-129: validation forward per particle
             vl, _ = self._val_plan.loss_grad(self._local, self._vx, self._vy, want_grad=False)
-            total_val = vl.sum() / self._M
-            if self._world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(total_val)
+            total_val = parallel.sum_over_ranks(vl.sum() / self._M)
         else:
             total_val = torch.zeros((), device="cuda")
         if self._step % 10 == 0:                                # SVGD.py:137-139
@@ -121,9 +107,9 @@ class SVGD(Optimizer):
 
     def result(self):
         import torch
+        from .. import parallel
         if self._world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self._all, self._local)
+            parallel.all_gather_rows(self._local, self._all)
         P = self._all.cpu().numpy()
         ensemble = Ensemble()
         for i in range(self._M):                                # SVGD.py:244-249

@@ -1,0 +1,115 @@
+"""One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU
+for tests).  What shards on this path:
+  * HMC / SGLD / SGD / BBB chains: independent units, no data-path collective; results are merged
+    once at the end (``merge_moment_chains`` / ``merge_sampled_chains``);
+  * SVGD particles: rows sharded by rank, ONE all-gather of the particle matrix per step
+    (``all_gather_rows``), Jacobi sweep.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def world_info() -> Tuple[int, int]:
+    """(rank, world) of the default group, (0, 1) when torch.distributed is not initialised."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """(first row, row count) of this rank's contiguous shard; n_items must divide evenly."""
+    if n_items % world != 0:
+        raise ValueError("the item count must be a multiple of the number of ranks")
+    n_local = n_items // world
+    return rank * n_local, n_local
+
+
+def all_gather_rows(local, out):
+    """out (world * n_local, D) <- concatenation of every rank's `local` (n_local, D)."""
+    import torch.distributed as dist
+    rank, world = world_info()
+    if world == 1:
+        if out.data_ptr() != local.data_ptr():
+            out.copy_(local)
+        return out
+    if dist.get_backend() == "gloo":           # gloo has no all_gather_into_tensor on every build
+        parts = [out[i * local.shape[0]:(i + 1) * local.shape[0]] for i in range(world)]
+        tmp = [p.clone() for p in parts]
+        dist.all_gather(tmp, local.contiguous())
+        for p, t in zip(parts, tmp):
+            p.copy_(t)
+    else:
+        dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def sum_over_ranks(t):
+    import torch.distributed as dist
+    if world_info()[1] > 1:
+        dist.all_reduce(t)
+    return t
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """max over ranks of a host scalar (bench.py: the step time of the slowest rank)."""
+    import torch
+    import torch.distributed as dist
+    if world_info()[1] == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def merge_moment_chains(mean, sq_mean, n: int):
+    """Pooled running moments of independent SGLD/SGD chains: sum_c n_c m_c / sum_c n_c."""
+    import torch
+    import torch.distributed as dist
+    if world_info()[1] == 1:
+        return mean, sq_mean, n
+    w = torch.tensor([float(n)], dtype=mean.dtype, device=mean.device)
+    m, s = mean * w, sq_mean * w
+    for t in (m, s, w):
+        dist.all_reduce(t)
+    return m / w, s / w, int(round(float(w.item())))
+
+
+def merge_sampled_chains(samples: Sequence, frequencies: Sequence[int]) -> Tuple[List, List[int]]:
+    """Concatenate the (samples, frequencies) of independent HMC chains from every rank."""
+    import torch.distributed as dist
+    if world_info()[1] == 1:
+        return list(samples), list(frequencies)
+    gathered = [None] * world_info()[1]
+    dist.all_gather_object(gathered, (list(samples), list(frequencies)))
+    out_s, out_f = [], []
+    for s, f in gathered:
+        out_s += s
+        out_f += f
+    return out_s, out_f

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Secondary measurements (GPU box): the other BASELINE.json configurations through the C-ABI step
+entry points, eager launches, HIP-event timed.  Prints one JSON line per configuration.
+(bench.py is the headline; these numbers go to DESIGN.md / profiles/.)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bayesian_inference_for_nn_amd import _lib, engine, synth  # noqa: E402
+
+
+def timed(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters   # us
+
+
+def main():
+    only = sys.argv[1:] or ["c1", "c3", "c4", "c5"]
+    dev = "cuda"
+    if "c1" in only:   # SGD linreg 1->1, batch 64 and whole set
+        x, y = synth.linreg(600)
+        spec = engine.MLPSpec((1, 1), ("linear",), "mse")
+        plan = engine.MLPPlan(spec, max_batch=600)
+        th = torch.tensor([0.3, -0.1], device=dev)
+        loss = torch.zeros(1, device=dev)
+        xd, yd = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
+        for b in (64, 480):
+            us = timed(lambda: plan.sgd_step(th, xd, yd, 1e-3, loss, batch=b), 500)
+            print(json.dumps({"config": "C1 SGD linreg 1->1", "batch": b, "us_per_step": round(us, 2), "steps_per_s": round(1e6 / us, 1)}))
+    if "c4" in only:   # BBB 784->400->400->10
+        dims = (784, 400, 400, 10)
+        spec = engine.MLPSpec(dims, ("relu", "relu", "softmax"), "scce")
+        plan = engine.MLPPlan(spec, max_batch=1024)
+        D = spec.n_params
+        x_h, y_h = synth.mnist_like(48000)
+        x, y = torch.as_tensor(x_h).to(dev), torch.as_tensor(y_h).to(dev)
+        mu, rho, w = torch.zeros(D, device=dev), torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        cost = torch.zeros(4, device=dev)
+        idx_h, sizes = synth.batch_plan(48000, 1024, 64)
+        idx = torch.as_tensor(idx_h).to(dev)
+        k = [0]
+
+        def step():
+            s = k[0] % 64
+            k[0] += 1
+            plan.bbb_step(mu, rho, w, x, y, 5e-4, 0.3, 0.0, 1.0, k[0], 2024, cost, batch=sizes[s], row_idx=idx[s])
+        us = timed(step, 300)
+        vplan = engine.MLPPlan(spec, max_batch=6000)
+        xv = x[:6000].contiguous()
+        yv = y[:6000].contiguous()
+        usv = timed(lambda: vplan.loss_grad(w, xv, yv, want_grad=False), 100)
+        print(json.dumps({"config": "C4 BBB 784->400->400->10 B=1024", "us_per_step": round(us, 2), "steps_per_s": round(1e6 / us, 1),
+                          "tflops": round(2292e6 / us / 1e6, 2), "validation_forward_us": round(usv, 2),
+                          "steps_per_s_with_reference_validation": round(1e6 / (us + 0.9 * usv), 1), "cost": float(cost[0])}))
+    if "c3" in only:   # HMC moons 2->50->2, L=20
+        xm, ym = synth.moons(2000)
+        xm, ym = xm[:1600], ym[:1600]
+        spec = engine.MLPSpec((2, 50, 2), ("relu", "softmax"), "scce")
+        for chains in (1, 8, 64):
+            plan = engine.MLPPlan(spec, max_batch=1600, max_particles=chains)
+            q = torch.zeros((chains, spec.n_params), device=dev)
+            stats = torch.zeros((chains, 8), device=dev)
+            xd, yd = torch.as_tensor(xm).to(dev), torch.as_tensor(ym).to(dev)
+            k = [0]
+
+            def step():
+                k[0] += 1
+                plan.hmc_step(q, xd, yd, 20, 0.002, 0.5, 0.0, 1.0, np.random.default_rng(k[0]).random(chains), k[0], 7, stats)
+            us = timed(step, 50)
+            print(json.dumps({"config": "C3 HMC moons 2->50->2 L=20 N=1600", "chains_on_gpu": chains, "us_per_sample": round(us, 1),
+                              "samples_per_s_per_chain": round(1e6 / us, 1), "samples_per_s_aggregate": round(chains * 1e6 / us, 1),
+                              "grad_evals_per_s": round(chains * 21 * 1e6 / us, 1), "accept_rate_last": float(stats[:, 0].mean())}))
+    if "c5" in only:   # SVGD 64 particles 784->200->10
+        dims = (784, 200, 10)
+        spec = engine.MLPSpec(dims, ("relu", "softmax"), "scce")
+        M, D = 64, spec.n_params
+        plan = engine.MLPPlan(spec, max_batch=1024, max_particles=M)
+        x_h, y_h = synth.mnist_like(48000)
+        x, y = torch.as_tensor(x_h).to(dev), torch.as_tensor(y_h).to(dev)
+        idx_h, sizes = synth.batch_plan(48000, 1024, 16)
+        idx = torch.as_tensor(idx_h).to(dev)
+        loss = torch.zeros(1, device=dev)
+        for sweep, scale in (("gauss_seidel", 1.0), ("jacobi", 1.0), ("gauss_seidel", 0.001)):
+            p = torch.empty((M, D), device=dev)
+            engine.fill_normal(p, 1, _lib.STREAM_INIT, 0, 0.0, scale)
+            am, av = torch.zeros((M, D), device=dev), torch.zeros((M, D), device=dev)
+            k = [0]
+
+            def step():
+                s = k[0] % 16
+                k[0] += 1
+                snap = p.clone() if sweep == "jacobi" else p
+                plan.svgd_step(p, snap, 0, am, av, x, y, 0.01, 1.0, k[0], loss, sweep=sweep, batch=sizes[s], row_idx=idx[s])
+            us = timed(step, 20)
+            print(json.dumps({"config": "C5 SVGD M=64 784->200->10 B=1024 1 GPU", "sweep": sweep, "init_scale": scale,
+                              "us_per_step": round(us, 1), "svgd_steps_per_s": round(1e6 / us, 2),
+                              "particle_grad_steps_per_s": round(M * 1e6 / us, 1), "tflops": round(45.2e9 / us / 1e6, 2),
+                              "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
