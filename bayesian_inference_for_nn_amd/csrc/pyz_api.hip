@@ -294,7 +294,8 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
                           hipStream_t st) {
   if (can_fuse(m)) {
-    float *xb = (want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
+    static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 0);  // 1: forward leaves a contiguous batch copy
+    float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
     launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb);
     launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
     if (want_grad) {
@@ -887,7 +888,7 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
     g.aux_pstride = (long long)m->max_batch * K;
     g.act = m->acts[layer - 1];
     g.vec = (N % 8 == 0) && (m->w_off[layer] % 4 == 0) && (P == 1 || m->D % 4 == 0) && aligned16(d_theta) ? 1 : 0;
-  } else {
+  } else if (kind == 0) {
     if (layer == 0) {
       g.in = d_x;
       g.in_pstride = 0;
@@ -897,22 +898,19 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
       g.in_pstride = (long long)m->max_batch * K;
     }
     g.lda = K;
-    if (kind == 0) {
-      g.out = m->act[layer];
-      g.out_pstride = (long long)m->max_batch * N;
-      g.act = m->acts[layer];
-      g.vec = (K % 8 == 0) && aligned16(g.in) ? 1 : 0;
-    } else {
-      g.aux = m->delta[layer];
-      g.aux_pstride = (long long)m->max_batch * N;
-      g.out = d_grad;
-      g.out_pstride = m->D;
-    }
+    g.out = m->act[layer];
+    g.out_pstride = (long long)m->max_batch * N;
+    g.act = m->acts[layer];
+    g.vec = (K % 8 == 0) && aligned16(g.in) ? 1 : 0;
   }
+  WgradArgs u{};
+  u.mode = PYZ_UPD_NONE;
+  u.grad = d_grad;
+  u.grad_pstride = m->D;
   for (int i = 0; i < iters; ++i) {
     if (kind == 0) pyz_launch_fwd(g, batch, P, st);
     else if (kind == 1) pyz_launch_bwd_data(g, batch, P, st);
-    else pyz_launch_bwd_weight(g, batch, P, st);
+    else launch_wgrad_all(m, P, d_x, d_row_idx, batch, m->ctl, u, st, nullptr);  // the launch the step uses (all layers)
   }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;

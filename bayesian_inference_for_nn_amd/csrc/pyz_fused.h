@@ -328,9 +328,26 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int se = (steps * (w + 1)) / S;
   PYZ_STAMP(2, 1);
   if (idx) {
-    pyz_wgrad_steps<16, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
-    pyz_wgrad_steps<4, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
-    pyz_wgrad_steps<1, true>(s, se, acc, ap, dp, idx, ly.lda, N, batch, h, r, is_w, is_b);
+    // gathered rows: the 64 row indices of a 32-step chunk come from ONE coalesced load (lane j
+    // holds the index of batch row 2*s0 + j) and reach the step that needs them by a lane
+    // permute, so the pipelined operand loads never wait on an index load
+    for (int s0 = s; s0 < se; s0 += 32) {
+      const int idxv = idx[min(2 * s0 + l, batch - 1)];
+      const int lda = ly.lda;
+      pyz_steps1_all(
+          s0, min(s0 + 32, se), acc,
+          [&](int st, float &a, float &d) {
+            const int bc = min(2 * st + h, batch - 1);
+            const long long row = __shfl(idxv, 2 * (st - s0) + h, 64);
+            a = ap[row * lda];
+            d = dp[(long long)bc * N];
+          },
+          [&](int st, float &a, float &d) {
+            const bool vb = 2 * st + h < batch;
+            a = vb ? (is_w ? a : (is_b ? 1.0f : 0.0f)) : 0.0f;
+            d = vb ? d : 0.0f;
+          });
+    }
   } else {
     pyz_wgrad_accumulate(acc, ap, dp, ly.lda, N, batch, s, se, h, is_w, is_b);
   }

@@ -162,10 +162,11 @@ int pyz_predict(pyz_mlp *mlp, const float *d_weights, int n_samples, const float
 int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step,
                     float mean, float std, void *stream);
 
-/* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE Dense kernel of
- * `layer` on the workspace left by the last pyz_mlp_loss_grad call with the same
- * arguments.  kind: 0 = forward (G1), 1 = data gradient, 2 = weight gradient (G3).
- * d_grad (P, D) receives the weight gradient for kind 2. */
+/* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE kernel of the
+ * gradient step on the workspace left by the last pyz_mlp_loss_grad call with the same
+ * arguments.  kind: 0 = k_dense_fwd of `layer` (G1), 1 = k_dense_bwd_data of `layer`,
+ * 2 = k_wgrad_all, the weight gradients of ALL layers (G3; `layer` ignored), written to
+ * d_grad (P, D). */
 int pyz_bench_dense_kernel(pyz_mlp *mlp, int kind, int layer, const float *d_theta, int n_particles,
                            const float *d_x, const int32_t *d_row_idx, int batch, float *d_grad,
                            int iters, void *stream);
