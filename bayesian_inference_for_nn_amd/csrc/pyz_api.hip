@@ -8,6 +8,7 @@
 #include "pyz_common.h"
 #include "pyz_fused.h"
 #include "pyz_gemm.h"
+#include "pyz_hmc_fused.h"
 #include "pyz_kernels.h"
 #include "pyz_rng.h"
 
@@ -700,6 +701,55 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   float *energies = m->scal + m->max_p;  // [P*8]
   float *unif = m->scal + 9 * m->max_p;  // [P]
   PYZ_HIP(hipMemcpyAsync(unif, h_uniform, sizeof(float) * P, hipMemcpyHostToDevice, st));
+  {
+    // small 2-layer models: the whole proposal in one workgroup per chain (pyz_hmc_fused.h)
+    const int allow_fused = pyz_env_int("PYZ_HMC_FUSED", 1);  // read per call: tests flip it
+    const int I = m->dims[0], H = m->dims[1], C = m->L == 2 ? m->dims[2] : 0;
+    const int MIC = (I <= 2 && C <= 2) ? 2 : ((I <= 4 && C <= 4) ? 4 : 8);
+    const size_t lds = m->L == 2 ? pyz_hmc_fused_lds_bytes(n_rows, MIC, MIC, C, (int)m->D, m->loss) : 0;
+    if (allow_fused && m->L == 2 && I <= PYZ_HF_MAXI && C <= PYZ_HF_MAXC && H + C <= 64 && lds <= 150 * 1024 &&
+        m->acts[0] != PYZ_ACT_SOFTMAX) {
+      HmcFusedArgs f{};
+      f.q = d_q;
+      f.x = d_x;
+      f.y = d_y;
+      f.N = n_rows;
+      f.I = I;
+      f.H = H;
+      f.C = C;
+      f.D = (int)m->D;
+      f.act_hidden = m->acts[0];
+      f.act_last = m->acts[1];
+      f.loss = m->loss;
+      f.L = L;
+      f.epsilon = epsilon;
+      f.m = mass;
+      f.prior_mean = prior_mean;
+      f.prior_sigma = prior_sigma;
+      f.burning = burning;
+      f.uniform = unif;
+      f.seed = seed;
+      f.step = (uint32_t)step;
+      f.unit_p = d_unit_p;
+      f.stats = d_stats;
+      void (*kern)(HmcFusedArgs) = nullptr;
+      const int bucket = (I <= 2 && C <= 2) ? 0 : ((I <= 4 && C <= 4) ? 1 : 2);
+#define PYZ_HF_PICK(ACT)                                                                         \
+  kern = bucket == 0 ? k_hmc_fused<2, 2, ACT> : (bucket == 1 ? k_hmc_fused<4, 4, ACT> : k_hmc_fused<8, 8, ACT>)
+      switch (m->acts[0]) {
+        case PYZ_ACT_RELU: PYZ_HF_PICK(PYZ_ACT_RELU); break;
+        case PYZ_ACT_TANH: PYZ_HF_PICK(PYZ_ACT_TANH); break;
+        case PYZ_ACT_SIGMOID: PYZ_HF_PICK(PYZ_ACT_SIGMOID); break;
+        default: PYZ_HF_PICK(PYZ_ACT_LINEAR); break;
+      }
+#undef PYZ_HF_PICK
+      if (lds > 64 * 1024)
+        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3(P), dim3(PYZ_HF_THREADS), lds, st, f);
+      PYZ_LAUNCH_CHECK();
+      return PYZ_OK;
+    }
+  }
   if ((rc = set_ctl(m, 0, n_rows, 0.0f, step, 0, 0, st))) return rc;
   HmcArgs a{};
   a.q = d_q;

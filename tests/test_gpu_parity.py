@@ -264,8 +264,12 @@ def test_bbb_step_matches_oracle(eng, name):
 
 
 # ------------------------------------------------------------------ HMC
-@pytest.mark.parametrize("name,L", [("moons", 5), ("linreg", 3), ("tiny_cls", 0)])
-def test_hmc_step_matches_oracle(eng, name, L):
+@pytest.mark.parametrize("name,L,fused", [("moons", 5, 1), ("moons", 5, 0), ("linreg", 3, 1), ("tiny_cls", 0, 1),
+                                          ("tiny_cls", 2, 0), ("reg3", 2, 1)])
+def test_hmc_step_matches_oracle(eng, name, L, fused, monkeypatch):
+    """fused = 1: small 2-layer models run the single-workgroup kernel (pyz_hmc_fused.h);
+    fused = 0 forces the generic multi-launch path on the same inputs."""
+    monkeypatch.setenv("PYZ_HMC_FUSED", str(fused))
     spec, n = SPECS[name]
     x, y, q0 = make(spec, n, seed=41, scale=0.2)
     D = spec.n_params
