@@ -209,29 +209,33 @@ __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap,
                                                    const int N, const int vec, const int w, const int S, const int h,
                                                    float *gp = nullptr) {
   const float bias = wp[(long long)K * N];  // issued first, consumed last
+  // The S waves of a workgroup take INTERLEAVED 8-wide chunks of K (wave w: chunks w, w+S, ...):
+  // at any moment the workgroup reads S adjacent chunks = a few whole 128-B lines per input row,
+  // which stay in the 32 KiB L1 and are shared by the waves.  Contiguous per-wave K ranges put
+  // S x 32 different lines in flight (more than the L1 holds) and refetch every line per 16-B piece.
   const int c8 = vec ? (K >> 3) : 0;
   pyz_steps4_all(
-      (c8 * w) / S, (c8 * (w + 1)) / S, acc,
-      [&](int c, float4 &a4, float4 &b4) {
-        const int k = 8 * c + 4 * h;
+      0, (c8 - w + S - 1) / S, acc,
+      [&](int u, float4 &a4, float4 &b4) {
+        const int k = 8 * (w + S * u) + 4 * h;
         a4 = *reinterpret_cast<const float4 *>(ap + k);
         const float *bp = wp + (long long)k * N;
         b4 = make_float4(bp[0], bp[N], bp[2 * (long long)N], bp[3 * (long long)N]);
       },
-      [&](int c, const float4 &a4) {
-        if (gp) *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
+      [&](int u, const float4 &a4) {
+        if (gp) *reinterpret_cast<float4 *>(gp + 8 * (w + S * u) + 4 * h) = a4;
       });
   const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
   pyz_steps1_all(
-      (steps * w) / S, (steps * (w + 1)) / S, acc,
-      [&](int s, float &a, float &b) {
-        const int kk = t0 + 2 * s + h;
+      0, (steps - w + S - 1) / S, acc,
+      [&](int u, float &a, float &b) {
+        const int kk = t0 + 2 * (w + S * u) + h;
         const int kc = kk < K ? kk : 0;
         a = ap[kc];
         b = wp[(long long)kc * N];
       },
-      [&](int s, float &a, float &b) {
-        const int kk = t0 + 2 * s + h;
+      [&](int u, float &a, float &b) {
+        const int kk = t0 + 2 * (w + S * u) + h;
         const bool vk = kk < K;
         if (gp && vk) gp[kk] = a;
         a = vk ? a : 0.0f;
