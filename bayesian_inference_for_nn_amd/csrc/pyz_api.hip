@@ -828,7 +828,7 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     return pyz_fail(PYZ_E_INVALID, "the Gauss-Seidel sweep needs the whole particle matrix on this device");
   if (n_total > 1024) return pyz_fail(PYZ_E_INVALID, "more than 1024 particles");
   if ((rc = need_grad(m, n_local))) return rc;
-  const int nblk = std::max(1, std::min(256, cdiv(m->D, 512)));
+  const int nblk = cdiv(m->D, PYZ_SVGD_BLOCK_ELEMS);  // one float64 partial per workgroup of k_svgd_dist
   const int rows_at_once = sweep == PYZ_SWEEP_JACOBI ? n_local : 1;
   if ((rc = need_part2(m, (size_t)rows_at_once * nblk * n_total + 8))) return rc;
   hipStream_t st = as_stream(stream);
@@ -859,15 +859,16 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
   a.gamma = gamma;
   a.part = full(m)->x.part2;
   a.nblk = nblk;
-  const size_t lds = sizeof(double) * (size_t)(n_total + 16);
+  const size_t lds = sizeof(double) * (size_t)(5 * n_total);
+  const int jgroups = cdiv(n_total, 8);
   if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
-    hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, n_local), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
   } else {
     for (int i = 0; i < n_local; ++i) {
       a.i_local = i;
-      hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, 1), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, 1), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
     }
   }

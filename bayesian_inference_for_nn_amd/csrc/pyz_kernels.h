@@ -450,41 +450,93 @@ struct SvgdArgs {
 
 // partial squared distances  sum_d (x_i[d] - x_j[d])^2  of row i against every j, in
 // float64 (SVGD.py:198-201 evaluates them on the float64 particle matrix).
-// grid = (nblk, rows); each workgroup owns a D-chunk, each wave a subset of the j's;
-// lanes sweep the chunk and combine with wave shuffles only (no LDS, no barrier).
-__global__ void k_svgd_dist(SvgdArgs g) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
-  const int il = g.i_local >= 0 ? g.i_local : blockIdx.y;
+// grid = (nblk, ceil(M/8), rows), 256 threads.  A workgroup owns 2048 consecutive elements of D
+// and EIGHT rows j: each wave keeps its 512-element slice of x_i in registers and streams the
+// eight x_j slices with 16-B loads, all issued before the first use (one memory round trip per
+// workgroup); lanes combine with shuffles, the 4 waves through LDS; one partial per workgroup.
+// The (D-chunk x row-group) grid puts thousands of waves in flight: the pass is bandwidth-bound.
+#define PYZ_SVGD_PASS 2
+#define PYZ_SVGD_BLOCK_ELEMS (4 * PYZ_SVGD_PASS * 256)   // elements of D per workgroup
+
+__global__ void __launch_bounds__(256) k_svgd_dist(SvgdArgs g) {
+  __shared__ double wsum[4][8];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int il = g.i_local >= 0 ? g.i_local : blockIdx.z;
   const int i = g.row0 + il;
-  const long long chunk = (g.D + g.nblk - 1) / g.nblk;
-  const long long d0 = blockIdx.x * chunk, d1 = min(g.D, d0 + chunk);
-  const float *xi = g.all + (long long)i * g.D;
-  double *outp = g.part + ((long long)(g.i_local >= 0 ? 0 : blockIdx.y) * g.nblk + blockIdx.x) * g.M;
-  for (int j = w; j < g.M; j += nw) {
-    const float *xj = g.all + (long long)j * g.D;
-    double s = 0.0;
-    for (long long d = d0 + l; d < d1; d += 64) {
-      const double df = (double)xi[d] - (double)xj[d];
-      s += df * df;
-    }
-    s = pyz_wave_sum(s);
-    if (l == 0) outp[j] = s;
+  const int j0 = blockIdx.y * 8;
+  const long long base = (long long)blockIdx.x * PYZ_SVGD_BLOCK_ELEMS + (long long)w * PYZ_SVGD_PASS * 256;
+  const float *xi_p = g.all + (long long)i * g.D;
+  const bool vec_ok = (g.D % 4 == 0);   // rows 16-B aligned
+  float xi[PYZ_SVGD_PASS][4], xj[8][PYZ_SVGD_PASS][4];
+#pragma unroll
+  for (int ps = 0; ps < PYZ_SVGD_PASS; ++ps) {
+    const long long d = base + ps * 256 + 4 * l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xi[ps][q] = (d + q < g.D) ? xi_p[d + q] : 0.0f;
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float *xj_p = g.all + (long long)min(j0 + u, g.M - 1) * g.D;
+#pragma unroll
+    for (int ps = 0; ps < PYZ_SVGD_PASS; ++ps) {
+      const long long d = base + ps * 256 + 4 * l;
+      if (vec_ok && d + 3 < g.D) {
+        const float4 v = *reinterpret_cast<const float4 *>(xj_p + d);
+        xj[u][ps][0] = v.x; xj[u][ps][1] = v.y; xj[u][ps][2] = v.z; xj[u][ps][3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xj[u][ps][q] = (d + q < g.D) ? xj_p[d + q] : 0.0f;
+      }
+    }
+  }
+  double s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    double acc = 0.0;
+#pragma unroll
+    for (int ps = 0; ps < PYZ_SVGD_PASS; ++ps)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = base + ps * 256 + 4 * l + q < g.D;
+        const double df = in ? (double)xi[ps][q] - (double)xj[u][ps][q] : 0.0;
+        acc += df * df;
+      }
+    s[u] = pyz_wave_sum(acc);
+  }
+  if (l == 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wsum[w][u] = s[u];
+  }
+  __syncthreads();
+  double *outp = g.part + ((long long)(g.i_local >= 0 ? 0 : blockIdx.z) * g.nblk + blockIdx.x) * g.M;
+  if (threadIdx.x < 8 && j0 + (int)threadIdx.x < g.M)
+    outp[j0 + threadIdx.x] = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
 }
 
 // phi_i = ( (sum_j K_ij) g_i + 2 gamma sum_j K_ij (x_i - x_j) ) / M   (SVGD.py:54-68)
 // followed by the particle's Keras legacy Adam step (SVGD.py:120, Appendix A3):
 //   m += (phi - m)(1 - b1); v += (phi^2 - v)(1 - b2); x -= lr_t m / (sqrt(v) + 1e-7)
-__global__ void k_svgd_update(SvgdArgs g) {
-  extern __shared__ double sd[];  // M doubles: K_ij
+// Rows j whose kernel value underflowed to exactly 0 (and j = i, whose difference is 0)
+// contribute exactly nothing to the repulsion sum and are not read: bit-identical, and in
+// the regime of far-apart particles the sweep touches one row instead of M.
+// grid = (ceil(D/256), rows), 256 threads; dynamic LDS = (5 M) doubles.
+__global__ void __launch_bounds__(256) k_svgd_update(SvgdArgs g) {
+  extern __shared__ double sd[];  // [M] K_ij, then [4][M] partial sums
   const int il = g.i_local >= 0 ? g.i_local : blockIdx.y;
   const int i = g.row0 + il;
   const double *pp = g.part + (long long)(g.i_local >= 0 ? 0 : blockIdx.y) * g.nblk * g.M;
-  for (int j = threadIdx.x; j < g.M; j += blockDim.x) {
-    double s = 0.0;
-    for (int b = 0; b < g.nblk; ++b) s += pp[(long long)b * g.M + j];
-    sd[j] = exp(-(double)g.gamma * s);
+  double *ps4 = sd + g.M;
+  {  // squared distances: the nblk partials of row j are summed by 4 threads (stride-4 slices), fixed order
+    const int q = threadIdx.x >> 6;
+    for (int j = threadIdx.x & 63; j < g.M; j += 64) {
+      double s = 0.0;
+      for (int b = q; b < g.nblk; b += 4) s += pp[(long long)b * g.M + j];
+      ps4[q * g.M + j] = s;
+    }
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < g.M; j += blockDim.x)
+    sd[j] = exp(-(double)g.gamma * ((ps4[j] + ps4[g.M + j]) + (ps4[2 * g.M + j] + ps4[3 * g.M + j])));
   __syncthreads();
   float ksum = 0.0f;
   for (int j = 0; j < g.M; ++j) ksum += (float)sd[j];
@@ -492,7 +544,11 @@ __global__ void k_svgd_update(SvgdArgs g) {
   if (d >= g.D) return;
   const float xi = g.all[(long long)i * g.D + d];
   double rep = 0.0;
-  for (int j = 0; j < g.M; ++j) rep += sd[j] * ((double)xi - (double)g.all[(long long)j * g.D + d]);
+  for (int j = 0; j < g.M; ++j) {
+    const double kj = sd[j];
+    if (kj == 0.0 || j == i) continue;   // wave-uniform
+    rep += kj * ((double)xi - (double)g.all[(long long)j * g.D + d]);
+  }
   rep *= 2.0 * (double)g.gamma;
   const long long o = (long long)il * g.D + d;
   const float phi = (ksum * g.grad[o] + (float)rep) / (float)g.M;
