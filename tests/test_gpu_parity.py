@@ -46,6 +46,10 @@ SPECS = {
     "reg3": (o_mlp.MLPSpec((4, 6, 6, 2), ("tanh", "sigmoid", "linear"), "mse"), 37),
     "mnist_small_batch": (o_mlp.MLPSpec((784, 200, 10), ("relu", "softmax"), "scce"), 96),
     "wide3": (o_mlp.MLPSpec((64, 40, 24, 10), ("relu", "relu", "softmax"), "scce"), 130),
+    # last layer wider than one 32-column tile: the unfused path (separate loss / gradient / update kernels)
+    "many_classes": (o_mlp.MLPSpec((12, 20, 40), ("tanh", "softmax"), "scce"), 70),
+    "wide_regression": (o_mlp.MLPSpec((9, 16, 48), ("relu", "linear"), "mse"), 33),
+    "single_row": (o_mlp.MLPSpec((8, 8, 3), ("sigmoid", "softmax"), "scce"), 1),
 }
 
 
@@ -167,8 +171,21 @@ def test_sgd_steps_match_oracle(eng):
     close(th, st.theta, what="theta")
 
 
+def test_sgd_step_unfused_path(eng):
+    spec, n = SPECS["wide_regression"]
+    x, y, theta = make(spec, n, seed=77)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n)
+    th, loss = dev(theta), torch.zeros(1, device="cuda")
+    st = o_sgd.SGDState(theta)
+    for _ in range(3):
+        plan.sgd_step(th, dev(x), ydev(spec, y), 0.05, loss)
+        rl, _ = o_sgd.sgd_step(st, x, y, spec, 0.05)
+        close(loss, [rl], what="loss")
+    close(th, st.theta, what="theta")
+
+
 # ------------------------------------------------------------------ SGLD
-@pytest.mark.parametrize("name", ["tiny_cls", "wide3"])
+@pytest.mark.parametrize("name", ["tiny_cls", "wide3", "many_classes", "wide_regression"])
 def test_sgld_step_injected_and_device_noise(eng, name):
     spec, n = SPECS[name]
     x, y, theta = make(spec, n, seed=11)
@@ -235,7 +252,7 @@ def test_sgld_run_matches_stepwise_oracle(eng, use_graph):
 
 
 # ------------------------------------------------------------------ BBB
-@pytest.mark.parametrize("name", ["tiny_cls", "reg3", "wide3"])
+@pytest.mark.parametrize("name", ["tiny_cls", "reg3", "wide3", "many_classes"])
 def test_bbb_step_matches_oracle(eng, name):
     spec, n = SPECS[name]
     x, y, mu0 = make(spec, n, seed=31)
