@@ -55,6 +55,19 @@ def host_cores() -> int:
     return min(n, 32)
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE
+    passes, KB units, FETCH_SIZE calibrated on this kernel's known byte count as
+    MI355X_MICROARCH.md section HBM prescribes for non-16-B/lane access).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))["kernels"][kernel.split("[")[0]]
+        return int(rec["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(budget_s: float = 12.0):
     """Time the eager CPU restatement (reference op granularity) on a bounded sample."""
     import torch
@@ -93,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel timing (used for the PMC passes)")
     args = ap.parse_args()
 
     import torch
@@ -158,7 +172,7 @@ def main():
         raise SystemExit(f"bench.py: non-finite loss {last_loss} on rank {rank}")
 
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         # dominant kernel, timed alone with HIP events on the bench stream
         iters = 300
         row = idx[0].contiguous()
@@ -188,7 +202,7 @@ def main():
         step_us = dt / args.steps * 1e6
         roof = {"bound": "mfma", "kernel": best[0], "kernel_us": round(best[1], 3), "flop_per_launch": flop,
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(best[0]),
                 "whole_step": {"flop": FLOP_PER_STEP, "bytes": BYTES_PER_STEP, "us": round(step_us, 3),
                                "tflops": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12, 3),
                                "frac_mfma": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
