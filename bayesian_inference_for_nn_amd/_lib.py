@@ -39,9 +39,9 @@ SIGNATURES = {
     "pyz_sgld_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _i64, _u64, _p, _p, _p]),
     "pyz_sgld_run": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _i64, _i64, _u64,
                                _p, C.c_int, _p]),
-    "pyz_bbb_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _f, _f, _f, _i64, _u64, _p, _p, _p]),
-    "pyz_hmc_step": (C.c_int, [_p, _p, C.c_int, _p, _p, C.c_int, C.c_int, _f, _f, _f, _f, C.c_int, C.POINTER(_f), _i64,
-                               _u64, _p, _p, _p]),
+    "pyz_bbb_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _f, _f, _f, _p, _p, _i64, _u64, _p, _p, _p]),
+    "pyz_hmc_step": (C.c_int, [_p, _p, C.c_int, _p, _p, C.c_int, C.c_int, _f, _f, _f, _f, _p, _p, C.c_int, C.POINTER(_f),
+                               _i64, _u64, _p, _p, _p]),
     "pyz_svgd_step": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_int, _f, _f, _i64,
                                 C.c_int, _p, _p]),
     "pyz_predict": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p, _p, _p]),

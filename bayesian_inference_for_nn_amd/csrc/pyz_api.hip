@@ -642,7 +642,8 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
 // ---------------------------------------------------------------- B2-B4
 int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float *d_x, const void *d_y,
                  const int32_t *d_row_idx, int batch, float lr, float alpha, float prior_mean, float prior_rho,
-                 int64_t step, uint64_t seed, const float *d_eps, float *d_cost, void *stream) {
+                 const float *d_prior_mean_vec, const float *d_prior_rho_vec, int64_t step, uint64_t seed,
+                 const float *d_eps, float *d_cost, void *stream) {
   int rc = check_call(m, 1, batch);
   if (rc) return rc;
   if ((rc = check_loss_combo(m))) return rc;
@@ -662,6 +663,8 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   a.alpha = alpha;
   a.prior_mean = prior_mean;
   a.prior_rho = prior_rho;
+  a.pm_vec = d_prior_mean_vec;
+  a.pr_vec = d_prior_rho_vec;
   a.seed = seed;
   a.step = (uint32_t)step;
   a.eps = d_eps;
@@ -685,8 +688,9 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
 
 // ---------------------------------------------------------------- H2-H5
 int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_y, int n_rows, int L, float epsilon,
-                 float mass, float prior_mean, float prior_sigma, int burning, const float *h_uniform, int64_t step,
-                 uint64_t seed, const float *d_unit_p, float *d_stats, void *stream) {
+                 float mass, float prior_mean, float prior_sigma, const float *d_prior_mean_vec,
+                 const float *d_prior_sigma_vec, int burning, const float *h_uniform, int64_t step, uint64_t seed,
+                 const float *d_unit_p, float *d_stats, void *stream) {
   int rc = check_call(m, P, n_rows);
   if (rc) return rc;
   if ((rc = check_loss_combo(m))) return rc;
@@ -707,7 +711,7 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
     const int I = m->dims[0], H = m->dims[1], C = m->L == 2 ? m->dims[2] : 0;
     const int MIC = (I <= 2 && C <= 2) ? 2 : ((I <= 4 && C <= 4) ? 4 : 8);
     const size_t lds = m->L == 2 ? pyz_hmc_fused_lds_bytes(n_rows, MIC, MIC, C, (int)m->D, m->loss) : 0;
-    if (allow_fused && m->L == 2 && I <= PYZ_HF_MAXI && C <= PYZ_HF_MAXC && H + C <= 64 && lds <= 150 * 1024 &&
+    if (allow_fused && !d_prior_mean_vec && !d_prior_sigma_vec && m->L == 2 && I <= PYZ_HF_MAXI && C <= PYZ_HF_MAXC && H + C <= 64 && lds <= 150 * 1024 &&
         m->acts[0] != PYZ_ACT_SOFTMAX) {
       HmcFusedArgs f{};
       f.q = d_q;
@@ -760,6 +764,8 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   a.m = mass;
   a.prior_mean = prior_mean;
   a.prior_sigma = prior_sigma;
+  a.pm_vec = d_prior_mean_vec;
+  a.ps_vec = d_prior_sigma_vec;
   a.n_train = (float)n_rows;
   a.seed = seed;
   a.step = (uint32_t)step;

@@ -208,6 +208,7 @@ struct BbbArgs {
   const float *grad;
   long long D;
   float lr, alpha, prior_mean, prior_rho;
+  const float *pm_vec, *pr_vec;  // optional per-element prior mean / rho (list-valued GaussianPrior); else the scalars
   uint64_t seed;
   uint32_t step;
   const float *eps;      // optional injected N(0,1)
@@ -241,15 +242,16 @@ __global__ void k_bbb_sample(BbbArgs g) {
   if (e0 < g.D) {
     float z[4];
     pyz_bbb_eps(g, t, z);
-    const float sp = pyz_softplus(g.prior_rho), lsp = logf(sp);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = e0 + j;
       if (e < g.D) {
+        const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
+        const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), lsp = logf(sp);
         const float mu = g.mu[e], sg = pyz_softplus(g.rho[e]);
         const float w = z[j] * sg + mu;
         g.w[e] = w;
-        const float a = (w - mu) / sg, b = (w - g.prior_mean) / sp;
+        const float a = (w - mu) / sg, b = (w - pmean) / sp;
         const float lq = -0.5f * a * a - logf(sg) - PYZ_LOG_SQRT_2PI;
         const float lp = -0.5f * b * b - lsp - PYZ_LOG_SQRT_2PI;
         kl += (double)lq - (double)lp;
@@ -272,17 +274,18 @@ __global__ void k_bbb_update(BbbArgs g) {
   if (e0 < g.D) {
     float z[4];
     pyz_bbb_eps(g, t, z);
-    const float sp = pyz_softplus(g.prior_rho), isp2 = 1.0f / (sp * sp);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = e0 + j;
       if (e < g.D) {
+        const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
+        const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), isp2 = 1.0f / (sp * sp);
         const float mu = g.mu[e], rho = g.rho[e], w = g.w[e];
         const float sg = pyz_softplus(rho), sig = pyz_sigmoid(rho);
         const float d = w - mu, is2 = 1.0f / (sg * sg);
         const float g_mu = g.alpha * d * is2;
         const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
-        const float g_w = g.grad[e] + g.alpha * (-d * is2 + (w - g.prior_mean) * isp2);
+        const float g_w = g.grad[e] + g.alpha * (-d * is2 + (w - pmean) * isp2);
         g.mu[e] = mu - g.lr * (g_mu + g_w);
         g.rho[e] = rho - g.lr * (z[j] * sig * g_w + g_rho);
       }
@@ -305,6 +308,7 @@ struct HmcArgs {
   const float *grad;     // (P, D) d loss / d q (mean loss)
   long long D;
   float m, prior_mean, prior_sigma, n_train;
+  const float *pm_vec, *ps_vec;  // optional per-element prior mean / sigma (D), shared by the chains
   float kick1, kick2;    // p -= kick1 * dU; p -= kick2 * dU  (kick2 = 0 when unused)
   float drift;           // q += drift * p   (0 when unused)
   uint64_t seed;
@@ -331,17 +335,18 @@ __global__ void k_hmc_begin(HmcArgs g) {
       const float4 v = pyz_normal4(g.seed, PYZ_STREAM_HMC + 16u * (uint32_t)c, g.step, (uint64_t)t);
       z[0] = v.x; z[1] = v.y; z[2] = v.z; z[3] = v.w;
     }
-    const float ls = logf(g.prior_sigma);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = e0 + j;
       if (e < g.D) {
+        const float pmu = g.pm_vec ? g.pm_vec[e] : g.prior_mean, psg = g.ps_vec ? g.ps_vec[e] : g.prior_sigma;
+        const float ls = logf(psg);
         const float q = g.q[c * g.D + e];
         const float pm = g.m * z[j];
         g.p[c * g.D + e] = pm;
         g.qsave[c * g.D + e] = q;
         sp2 += (double)(pm * pm);
-        const float a = (q - g.prior_mean) / g.prior_sigma;
+        const float a = (q - pmu) / psg;
         slp += (double)(-0.5f * a * a - ls - PYZ_LOG_SQRT_2PI);
       }
     }
@@ -363,7 +368,8 @@ __global__ void k_hmc_kick_drift(HmcArgs g) {
   if (e >= g.D) return;
   const long long o = c * g.D + e;
   const float q = g.q[o];
-  const float dU = (q - g.prior_mean) / (g.prior_sigma * g.prior_sigma) + g.n_train * g.grad[o];
+  const float pmu = g.pm_vec ? g.pm_vec[e] : g.prior_mean, psg = g.ps_vec ? g.ps_vec[e] : g.prior_sigma;
+  const float dU = (q - pmu) / (psg * psg) + g.n_train * g.grad[o];
   float p = g.p[o];
   p = p - g.kick1 * dU;
   if (g.kick2 != 0.0f) p = p - g.kick2 * dU;
@@ -380,8 +386,9 @@ __global__ void k_hmc_end_energy(HmcArgs g) {
   if (e < g.D) {
     const float q = g.q[c * g.D + e], p = g.p[c * g.D + e];
     sp2 = (double)(p * p);
-    const float a = (q - g.prior_mean) / g.prior_sigma;
-    slp = (double)(-0.5f * a * a - logf(g.prior_sigma) - PYZ_LOG_SQRT_2PI);
+    const float pmu = g.pm_vec ? g.pm_vec[e] : g.prior_mean, psg = g.ps_vec ? g.ps_vec[e] : g.prior_sigma;
+    const float a = (q - pmu) / psg;
+    slp = (double)(-0.5f * a * a - logf(psg) - PYZ_LOG_SQRT_2PI);
   }
   const double s0 = pyz_block_sum(slp, sm);
   const double s1 = pyz_block_sum(sp2, sm);

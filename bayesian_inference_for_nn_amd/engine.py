@@ -177,28 +177,32 @@ class MLPPlan:
 
     # ------------------------------------------------------------------ B2-B4
     def bbb_step(self, mu, rho, w, x, y, lr, alpha, prior_mean, prior_rho, step, seed, cost_out, batch=None,
-                 row_idx=None, eps=None):
+                 row_idx=None, eps=None, prior_mean_vec=None, prior_rho_vec=None):
         for t, nm in ((mu, "mu"), (rho, "rho"), (w, "w")):
             _f32(t, (self.D,), nm)
-        if eps is not None:
-            _f32(eps, (self.D,), "eps")
+        for t, nm in ((eps, "eps"), (prior_mean_vec, "prior_mean_vec"), (prior_rho_vec, "prior_rho_vec")):
+            if t is not None:
+                _f32(t, (self.D,), nm)
         _f32(cost_out, name="cost_out")
         assert cost_out.numel() >= 3
         batch = int(batch if batch is not None else (row_idx.numel() if row_idx is not None else x.shape[0]))
         self._check_xy(x, y, row_idx, batch)
         check(self.lib.pyz_bbb_step(self.h, ptr(mu), ptr(rho), ptr(w), ptr(x), ptr(y), ptr(row_idx), batch, float(lr),
-                                    float(alpha), float(prior_mean), float(prior_rho), int(step), int(seed), ptr(eps),
-                                    ptr(cost_out), _stream()))
+                                    float(alpha), float(prior_mean), float(prior_rho), ptr(prior_mean_vec),
+                                    ptr(prior_rho_vec), int(step), int(seed), ptr(eps), ptr(cost_out), _stream()))
 
     # ------------------------------------------------------------------ H2-H5
     def hmc_step(self, q, x, y, L, epsilon, m, prior_mean, prior_sigma, uniforms, step, seed, stats_out, burning=False,
-                 unit_p=None):
+                 unit_p=None, prior_mean_vec=None, prior_sigma_vec=None):
         P = 1 if q.dim() == 1 else q.shape[0]
         _f32(q, name="q")
         assert q.numel() == P * self.D
         if unit_p is not None:
             _f32(unit_p, name="unit_p")
             assert unit_p.numel() == P * self.D
+        for t, nm in ((prior_mean_vec, "prior_mean_vec"), (prior_sigma_vec, "prior_sigma_vec")):
+            if t is not None:
+                _f32(t, (self.D,), nm)
         _f32(stats_out, name="stats_out")
         assert stats_out.numel() >= 8 * P
         n_rows = x.shape[0]
@@ -206,9 +210,9 @@ class MLPPlan:
         u = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float32).reshape(-1))
         assert u.size == P
         check(self.lib.pyz_hmc_step(self.h, ptr(q), P, ptr(x), ptr(y), n_rows, int(L), float(epsilon), float(m),
-                                    float(prior_mean), float(prior_sigma), 1 if burning else 0,
-                                    u.ctypes.data_as(C.POINTER(C.c_float)), int(step), int(seed), ptr(unit_p),
-                                    ptr(stats_out), _stream()))
+                                    float(prior_mean), float(prior_sigma), ptr(prior_mean_vec), ptr(prior_sigma_vec),
+                                    1 if burning else 0, u.ctypes.data_as(C.POINTER(C.c_float)), int(step), int(seed),
+                                    ptr(unit_p), ptr(stats_out), _stream()))
 
     # ------------------------------------------------------------------ V2-V4
     def svgd_step(self, particles, all_particles, row0, adam_m, adam_v, x, y, lr, gamma, t, loss_out, sweep="gauss_seidel",

@@ -50,8 +50,6 @@ class BBB(Optimizer):
                 self._prior._mean * self._pi + self._prior2._mean * (1 - self._pi),
                 sign * math.sqrt((self._prior._std_dev * self._pi) ** 2 + (self._prior2._std_dev * (1 - self._pi)) ** 2),
             )
-        else:
-            raise NotImplementedError("BBB kernels take a scalar GaussianPrior (mean, rho)")
         self._alpha = self._hyperparameters.alpha
         self._setup_backend(seed=kwargs.get("seed"))
         self._base_model = self._net
@@ -60,6 +58,11 @@ class BBB(Optimizer):
         mu, rho = self._prior.flat(self._net)                   # BBB.py:277-296: posterior <- prior (raw rho)
         self._mu = torch.as_tensor(mu.copy()).cuda()
         self._rho = torch.as_tensor(rho.copy()).cuda()
+        if self._prior.is_scalar():
+            self._pm, self._pr, self._pm_vec, self._pr_vec = float(self._prior._mean), float(self._prior._std_dev), None, None
+        else:                                                   # list-valued prior: no mixing (BBB.py:265), per-element vectors
+            self._pm, self._pr = 0.0, 1.0
+            self._pm_vec, self._pr_vec = self._mu.clone(), self._rho.clone()
         self._w = torch.zeros(self._D, device="cuda")
         self._cost = torch.zeros(4, device="cuda")
         self._weight_layers_indices = self._layer_indices()
@@ -75,8 +78,8 @@ class BBB(Optimizer):
         self._step += 1
         idx, b, _ = self._next_batch()
         self._plan.bbb_step(self._mu, self._rho, self._w, self._x_dev, self._y_dev, self._lr, self._alpha,
-                            self._prior._mean, self._prior._std_dev, self._step, self._seed, self._cost, batch=b,
-                            row_idx=idx)
+                            self._pm, self._pr, self._step, self._seed, self._cost, batch=b, row_idx=idx,
+                            prior_mean_vec=self._pm_vec, prior_rho_vec=self._pr_vec)
         likelihood = DeviceScalar(self._cost.clone(), 0)
         if save_document_path != None:
             with open(save_document_path, "a") as losses_file:

@@ -40,12 +40,15 @@ class HMC(Optimizer):
         if "nb_burn_epoch" in kwargs:
             # the reference tests one key and reads another (HMC.py:61-62); kept as written
             self._nb_burn_epoch = kwargs["nb_burn_epochs"]
-        if not self._prior_spec.is_scalar():
-            raise NotImplementedError("HMC kernels take a scalar GaussianPrior (mean, rho)")
-        self._prior_mean, self._prior_sigma = float(self._prior_spec._mean), float(self._prior_spec._std_dev)
         self._dataset_setup()
         # q <- prior mean (HMC.py:69-72)
-        mu, _ = self._prior_spec.flat(self._net)
+        mu, sg = self._prior_spec.flat(self._net)
+        if self._prior_spec.is_scalar():
+            self._prior_mean, self._prior_sigma = float(self._prior_spec._mean), float(self._prior_spec._std_dev)
+            self._pm_vec = self._ps_vec = None
+        else:                                                  # per-layer lists: per-element vectors on the device
+            self._prior_mean, self._prior_sigma = 0.0, 1.0
+            self._pm_vec, self._ps_vec = torch.as_tensor(mu.copy()).cuda(), torch.as_tensor(sg.copy()).cuda()
         self._q = torch.as_tensor(np.repeat(mu[None, :], self._n_chains, axis=0).copy()).cuda()
         self._stats = torch.zeros((self._n_chains, 8), device="cuda")
         self._step_count = 0
@@ -60,7 +63,8 @@ class HMC(Optimizer):
                     self._chain_samples[c].append(self._q[c].clone())
         uniforms = [random.random() for _ in range(self._n_chains)]      # HMC.py:91 host Mersenne Twister
         self._plan.hmc_step(self._q, self._x_dev, self._y_dev, int(self._L), self._epsilon, self._m, self._prior_mean,
-                            self._prior_sigma, uniforms, self._step_count, self._seed, self._stats, burning=burning)
+                            self._prior_sigma, uniforms, self._step_count, self._seed, self._stats, burning=burning,
+                            prior_mean_vec=self._pm_vec, prior_sigma_vec=self._ps_vec)
         self._step_count += 1
         stats = self._stats.cpu().numpy()
         self._total_runs += 1

@@ -120,10 +120,13 @@ int pyz_sgld_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, 
  * parameters (D each); eps ~ N(0,1) from Philox (seed, step) or d_eps.
  * Writes the sampled weights to d_w (D, used by the validation pass), the
  * cost (loss + alpha * (log q - log p)) to d_cost[0] and the data loss to
- * d_cost[1].  prior_rho is the raw rho: sigma_p = softplus(prior_rho). */
+ * d_cost[1].  prior_rho is the raw rho: sigma_p = softplus(prior_rho).  A list-valued
+ * GaussianPrior (GaussianPrior.py:50-69) is passed as the optional per-element vectors
+ * d_prior_mean_vec / d_prior_rho_vec (float32[D]; NULL = the scalars). */
 int pyz_bbb_step(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const float *d_x,
                  const void *d_y, const int32_t *d_row_idx, int batch, float lr, float alpha,
-                 float prior_mean, float prior_rho, int64_t step, uint64_t seed,
+                 float prior_mean, float prior_rho, const float *d_prior_mean_vec,
+                 const float *d_prior_rho_vec, int64_t step, uint64_t seed,
                  const float *d_eps, float *d_cost, void *stream);
 
 /* ---- H2-H5: one HMC proposal (HMC.py:74-104) for P independent chains on the
@@ -132,9 +135,12 @@ int pyz_bbb_step(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const floa
  * d_unit_p (P, D).  h_uniform[P] are the host uniforms of random.random();
  * burning != 0 forces acceptance.  Outputs (device, float32): d_stats (P, 8) =
  * {accepted, loss, U0, K0, U1, K1, log_ratio, 0}.  prior_sigma is the raw rho
- * (negative => NaN potential, every non-burn proposal rejected, HMC.py:149-159). */
+ * (negative => NaN potential, every non-burn proposal rejected, HMC.py:149-159).
+ * d_prior_mean_vec / d_prior_sigma_vec: optional per-element prior (float32[D], shared by the
+ * chains) for list-valued priors; NULL = the scalars. */
 int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const void *d_y,
                  int n_rows, int L, float epsilon, float m, float prior_mean, float prior_sigma,
+                 const float *d_prior_mean_vec, const float *d_prior_sigma_vec,
                  int burning, const float *h_uniform, int64_t step, uint64_t seed,
                  const float *d_unit_p, float *d_stats, void *stream);
 

@@ -280,6 +280,34 @@ def test_bbb_step_matches_oracle(eng, name):
     plan.close()
 
 
+def test_list_valued_priors_bbb_and_hmc(eng, monkeypatch):
+    """Per-layer GaussianPrior lists (GaussianPrior.py:50-69) reach the kernels as per-element vectors."""
+    spec, n = SPECS["tiny_cls"]
+    x, y, mu0 = make(spec, n, seed=91)
+    D = spec.n_params
+    sl = spec.layer_slices()
+    pm = np.zeros(D, np.float32); pr = np.zeros(D, np.float32)
+    pm[sl[0]], pr[sl[0]] = 0.2, 0.7
+    pm[sl[1]], pr[sl[1]] = -0.1, 1.3
+    rho0 = (np.random.default_rng(92).normal(size=D) * 0.2 - 0.5).astype(np.float32)
+    eps = o_philox.normal(3, 1, 1, D)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=2)
+    mu, rho, w, cost = dev(mu0), dev(rho0), torch.zeros(D, device="cuda"), torch.zeros(4, device="cuda")
+    plan.bbb_step(mu, rho, w, dev(x), ydev(spec, y), 1e-2, 0.3, 0.0, 1.0, 1, 3, cost, prior_mean_vec=dev(pm), prior_rho_vec=dev(pr))
+    out = o_bbb.bbb_step(mu0, rho0, eps, x, y, spec, 1e-2, 0.3, pm, pr)
+    close(mu, out["mu"], what="mu"); close(rho, out["rho"], what="rho")
+    assert abs(float(cost[0]) - out["cost"]) <= 1e-4 * abs(out["cost"]) + 1e-5
+    z = np.random.default_rng(93).normal(size=(1, D)).astype(np.float32)
+    q = dev(mu0.reshape(1, -1)); stats = torch.zeros((1, 8), device="cuda")
+    plan.hmc_step(q, dev(x), ydev(spec, y), 4, 0.002, 0.5, 0.0, 1.0, [0.0], 0, 1, stats, unit_p=dev(z), burning=True,
+                  prior_mean_vec=dev(pm), prior_sigma_vec=dev(pr))
+    r = o_hmc.hmc_step(mu0, z[0], x, y, spec, pm, pr, 4, 0.002, 0.5, u=0.0, burning=True)
+    close(q[0], r["q_proposed"], what="q")
+    s = stats.cpu().numpy()[0]
+    assert abs(s[2] - r["U0"]) <= 1e-4 * abs(r["U0"]) and abs(s[5] - r["K1"]) <= 1e-4 * abs(r["K1"])
+    plan.close()
+
+
 # ------------------------------------------------------------------ HMC
 @pytest.mark.parametrize("name,L,fused", [("moons", 5, 1), ("moons", 5, 0), ("linreg", 3, 1), ("tiny_cls", 0, 1),
                                           ("tiny_cls", 2, 0), ("reg3", 2, 1)])

@@ -169,6 +169,20 @@ def test_bbb_surface_matches_oracle_and_result_tuple():
     np.testing.assert_allclose(model._distributions[1]._tf_distribution.scale, o_bbb.softplus(rho)[48:], rtol=1e-4)
 
 
+def test_list_priors_through_the_surface():
+    ds = moons_dataset()
+    opt = BBB()
+    opt.compile(HyperParameters(lr=0.05, alpha=0.1, batch_size=128), MOONS_JSON, ds, verbose=False,
+                prior=GaussianPrior([0.0, 0.1], [-1.0, 0.5]), seed=4)
+    assert float(opt._mu[:48].abs().max()) == 0.0 and abs(float(opt._mu[60]) - 0.1) < 1e-7     # posterior <- prior, per layer
+    costs = [float(opt.step()) for _ in range(20)]
+    assert np.isfinite(costs).all() and not torch.equal(opt._mu[:48], torch.zeros(48, device="cuda"))
+    h = HMC()
+    h.compile(HyperParameters(epsilon=0.002, m=0.5, L=4), MOONS_JSON, ds, verbose=False, prior=GaussianPrior([0.0, 0.0], [1.0, 2.0]), seed=4)
+    h.train(5)
+    assert sum(h._frequency) == 6
+
+
 def test_svgd_surface():
     ds = moons_dataset()
     opt = SVGD()
