@@ -90,11 +90,15 @@ class SVGD(Optimizer):
             snapshot = self._all
         self._plan.svgd_step(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._x_dev, self._y_dev,
                              self._lr, self._gamma, self._step, self._loss_dev, sweep=self._sweep, batch=b, row_idx=idx)
-        total_loss = parallel.sum_over_ranks(self._loss_dev.clone())
+        total_loss = self._loss_dev.clone()
+        if self._world > 1:
+            parallel.sum_over_ranks(total_loss)
         loss = DeviceScalar(total_loss, 0)
         if self._val_n > 0:                                     # SVGD.py:126-129: validation forward per particle
             vl, _ = self._val_plan.loss_grad(self._local, self._vx, self._vy, want_grad=False)
-            total_val = parallel.sum_over_ranks(vl.sum() / self._M)
+            total_val = vl.sum() / self._M
+            if self._world > 1:
+                parallel.sum_over_ranks(total_val)
         else:
             total_val = torch.zeros((), device="cuda")
         if self._step % 10 == 0:                                # SVGD.py:137-139

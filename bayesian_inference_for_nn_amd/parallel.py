@@ -59,10 +59,10 @@ def all_gather_rows(local, out):
         if out.data_ptr() != local.data_ptr():
             out.copy_(local)
         return out
-    if dist.get_backend() == "gloo":           # gloo has no all_gather_into_tensor on every build
+    if dist.get_backend() == "gloo":           # CPU tests / several ranks sharing one GPU: staged through the host
         parts = [out[i * local.shape[0]:(i + 1) * local.shape[0]] for i in range(world)]
-        tmp = [p.clone() for p in parts]
-        dist.all_gather(tmp, local.contiguous())
+        tmp = [p.detach().cpu().clone() for p in parts]
+        dist.all_gather(tmp, local.detach().cpu().contiguous())
         for p, t in zip(parts, tmp):
             p.copy_(t)
     else:
@@ -73,7 +73,12 @@ def all_gather_rows(local, out):
 def sum_over_ranks(t):
     import torch.distributed as dist
     if world_info()[1] > 1:
-        dist.all_reduce(t)
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
     return t
 
 
