@@ -50,6 +50,8 @@ SPECS = {
     "many_classes": (o_mlp.MLPSpec((12, 20, 40), ("tanh", "softmax"), "scce"), 70),
     "wide_regression": (o_mlp.MLPSpec((9, 16, 48), ("relu", "linear"), "mse"), 33),
     "single_row": (o_mlp.MLPSpec((8, 8, 3), ("sigmoid", "softmax"), "scce"), 1),
+    "small_reg2": (o_mlp.MLPSpec((3, 5, 2), ("tanh", "linear"), "mse"), 45),      # 2 layers + MSE: fused HMC kernel
+    "hmc_regression": (o_mlp.MLPSpec((1, 1, 1), ("linear", "linear"), "mse"), 60),  # HMC_regression.py:36-39
 }
 
 
@@ -310,7 +312,8 @@ def test_list_valued_priors_bbb_and_hmc(eng, monkeypatch):
 
 # ------------------------------------------------------------------ HMC
 @pytest.mark.parametrize("name,L,fused", [("moons", 5, 1), ("moons", 5, 0), ("linreg", 3, 1), ("tiny_cls", 0, 1),
-                                          ("tiny_cls", 2, 0), ("reg3", 2, 1)])
+                                          ("tiny_cls", 2, 0), ("reg3", 2, 1), ("small_reg2", 3, 1), ("small_reg2", 3, 0),
+                                          ("hmc_regression", 4, 1)])
 def test_hmc_step_matches_oracle(eng, name, L, fused, monkeypatch):
     """fused = 1: small 2-layer models run the single-workgroup kernel (pyz_hmc_fused.h);
     fused = 0 forces the generic multi-launch path on the same inputs."""

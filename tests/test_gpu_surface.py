@@ -219,3 +219,17 @@ def test_bayesian_model_predict_matches_oracle():
     np.testing.assert_allclose(np.stack(samples), rs, atol=1e-5)
     np.testing.assert_allclose(mean, rm, atol=1e-5)
     assert np.array_equal(np.argmax(mean, axis=1), np.argmax(rm, axis=1))          # integer class labels bit-exact
+
+
+def test_compat_standins_run_a_reference_style_driver():
+    """compat/: `import tensorflow as tf` + `from Pyesian...` resolve to the stand-ins and a driver written in
+    the reference's style runs end to end on the GPU (run in-process: no exec after the GPU is initialised)."""
+    import os
+    import runpy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        runpy.run_path(os.path.join(root, "examples", "hmc_classification_compat.py"), run_name="__main__")
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))

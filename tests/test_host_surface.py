@@ -194,3 +194,28 @@ def test_all_five_methods_are_optimizers():
         with pytest.raises(AttributeError):
             inst.compile(HyperParameters(), sequential_json(2, [2], ["softmax"]), None, verbose=False, prior=None,
                          starting_model=None)       # missing hyper-parameter -> AttributeError, as the reference
+
+
+def test_compat_tensorflow_standin_builds_keras_json():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        import tensorflow as tf
+        from Pyesian.optimizers import HMC as HMC2
+        from Pyesian.optimizers.hyperparameters import HyperParameters as HP2
+        assert HMC2 is HMC and HP2 is HyperParameters
+        m = tf.keras.models.Sequential([tf.keras.layers.Flatten(input_shape=(28, 28)),
+                                        tf.keras.layers.Dense(16, activation='relu'),
+                                        tf.keras.layers.Dense(10, activation=tf.keras.activations.softmax)])
+        net = model_from_json(m.to_json())
+        assert net.dims == (784, 16, 10) and net.acts == ("relu", "softmax") and len(m.layers) == 3
+        x = tf.random.uniform(shape=(6, 1), minval=1, maxval=20, dtype=tf.float32)
+        y = 2 * x + 2
+        assert isinstance(y, tf.Tensor) and y.numpy().shape == (6, 1)
+        ds = tf.data.Dataset.from_tensor_slices((x, y))
+        assert int(ds.cardinality().numpy()) == 6
+        assert int(tf.argmax(np.array([[0.1, 0.9]]), axis=1).numpy()[0]) == 1
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
+        sys.modules.pop("tensorflow", None)
