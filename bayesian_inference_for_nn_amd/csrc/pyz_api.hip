@@ -297,12 +297,17 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
   if (can_fuse(m)) {
     static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 0);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
+    hipEvent_t *ev = m->probe;  // measurement only (pyz_sgld_profile)
+    if (ev) (void)hipEventRecord(ev[0], st);
     launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb);
+    if (ev) (void)hipEventRecord(ev[1], st);
     launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
+    if (ev) (void)hipEventRecord(ev[2], st);
     if (want_grad) {
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
       launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xb);
     }
+    if (ev) (void)hipEventRecord(ev[3], st);
     return;
   }
   launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
@@ -551,9 +556,10 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
   return PYZ_OK;
 }
 
-int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
-                 const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
-                 int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream) {
+static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
+                         const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
+                         int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream,
+                         hipEvent_t *events /* optional: 4 per step, recorded around the kernels (eager only) */) {
   if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
   int rc = check_loss_combo(m);
   if (rc) return rc;
@@ -632,11 +638,53 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
     }
     for (; s + G <= n_steps; s += G) PYZ_HIP(hipGraphLaunch(m->graph_exec, st));
   }
-  for (; s < n_steps; ++s)
+  for (; s < n_steps; ++s) {
+    m->probe = events ? events + 4 * (size_t)s : nullptr;
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
                      d_losses, st);
+  }
+  m->probe = nullptr;
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
+}
+
+int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
+                 const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
+                 int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream) {
+  return sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, seed,
+                       d_losses, use_graph, stream, nullptr);
+}
+
+// Measurement: n_steps eager SGLD steps with HIP events around the kernels of every step, on the
+// stream they are launched on.  h_avg_us[3] = average in-pipeline duration (microseconds, launch gap
+// included) of {hidden-layer forward kernels, k_head, data-gradient + k_wgrad_all}.  Same arguments
+// and effect on the chain as pyz_sgld_run.
+int pyz_sgld_profile(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
+                     const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
+                     int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, float *h_avg_us, void *stream) {
+  if (!m || !h_avg_us) return pyz_fail(PYZ_E_INVALID, "null argument");
+  if (!can_fuse(m)) return pyz_fail(PYZ_E_INVALID, "profile needs the fused step (last layer <= 32 wide)");
+  if (n_steps <= 0 || n_steps > 4096) return pyz_fail(PYZ_E_INVALID, "n_steps outside [1, 4096]");
+  hipStream_t st = as_stream(stream);
+  std::vector<hipEvent_t> ev((size_t)4 * n_steps);
+  for (auto &e : ev) PYZ_HIP(hipEventCreate(&e));
+  // one eager run of n_steps: the launches queue ahead of the GPU, so each kernel runs right behind
+  // its predecessor exactly as inside the replayed graph
+  int rc = sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, seed,
+                         d_losses, 0, stream, ev.data());
+  if (rc == PYZ_OK && hipStreamSynchronize(st) != hipSuccess) rc = pyz_fail(PYZ_E_HIP, "stream synchronize failed");
+  double acc[3] = {0, 0, 0};
+  if (rc == PYZ_OK) {
+    for (int s = 0; s < n_steps; ++s)
+      for (int k = 0; k < 3; ++k) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, ev[4 * (size_t)s + k], ev[4 * (size_t)s + k + 1]);
+        acc[k] += ms;
+      }
+    for (int k = 0; k < 3; ++k) h_avg_us[k] = (float)(acc[k] * 1e3 / n_steps);
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 // ---------------------------------------------------------------- B2-B4

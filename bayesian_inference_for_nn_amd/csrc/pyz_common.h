@@ -103,6 +103,7 @@ struct pyz_mlp {
   float *qsave = nullptr;                    // (P, D) HMC snapshot
   double *part = nullptr;                    // reduction partials
   int part_len = 0;
+  hipEvent_t *probe = nullptr;               // optional: 4 events recorded around the kernels of one fused step
   int cur_nblk = 0;                          // number of loss partials the last loss launch wrote per particle
   float *scal = nullptr;                     // small device scalars
   StepCtl *ctl = nullptr;                    // device StepCtl

@@ -175,6 +175,25 @@ class MLPPlan:
                                     n_steps, int(n0), int(slot0), int(seed), ptr(losses_out), 1 if use_graph else 0,
                                     _stream()))
 
+    def sgld_profile(self, theta, mean, sq_mean, x, y, row_idx, batch_sizes, lrs, n0, seed, losses_out, slot0=0):
+        """n eager steps with HIP events around each kernel; returns average microseconds of
+        (forward, head, weight gradient + update) inside the pipeline."""
+        n_steps = len(batch_sizes)
+        assert len(lrs) == n_steps and 0 < n_steps <= 4096
+        for t, nm in ((theta, "theta"), (mean, "mean"), (sq_mean, "sq_mean")):
+            _f32(t, (self.D,), nm)
+        self._check_xy(x, y, row_idx, 1)
+        if slot0 < 0 or row_idx.numel() < (slot0 + n_steps) * self.max_batch or losses_out.numel() < slot0 + n_steps:
+            raise ValueError("row_idx / losses_out too small")
+        if any(int(b) < 1 or int(b) > self.max_batch for b in batch_sizes):
+            raise ValueError("batch size outside the plan")
+        bs = (C.c_int32 * n_steps)(*[int(b) for b in batch_sizes])
+        lr = (C.c_float * n_steps)(*[float(v) for v in lrs])
+        out = (C.c_float * 3)()
+        check(self.lib.pyz_sgld_profile(self.h, ptr(theta), ptr(mean), ptr(sq_mean), ptr(x), ptr(y), ptr(row_idx), bs, lr,
+                                        n_steps, int(n0), int(slot0), int(seed), ptr(losses_out), out, _stream()))
+        return [float(v) for v in out]
+
     # ------------------------------------------------------------------ B2-B4
     def bbb_step(self, mu, rho, w, x, y, lr, alpha, prior_mean, prior_rho, step, seed, cost_out, batch=None,
                  row_idx=None, eps=None, prior_mean_vec=None, prior_rho_vec=None):

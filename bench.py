@@ -11,10 +11,10 @@ region; the timed region is K steps bracketed by barrier + synchronize; the time
 is the max over ranks and `value` the whole-job steps/s.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (the layer-0 Dense GEMM: forward or weight
-                gradient, whichever is slower): algorithmic FLOP per launch /
-                its average duration from HIP events around back-to-back launches
-                on the bench stream, against the dense fp32 MFMA peak.
+  roofline      the dominant kernel of the step (the slowest of k_dense_fwd, k_head,
+                k_wgrad_all): algorithmic FLOP per launch / its average in-pipeline
+                duration, measured live with HIP events recorded on the bench stream
+                around every kernel of 256 further steps, against the dense fp32 MFMA peak.
   cpu_baseline  the oracle's eager torch-CPU restatement of the same step
                 (oracle/torch_eager.py, kind "port") on the host cores.
 """
@@ -177,36 +177,37 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        # dominant kernel, timed alone with HIP events on the bench stream
-        iters = 300
-        row = idx[0].contiguous()
-        grad = torch.empty((1, D), device=dev)
-        yy = y
+        # The step is three kernels (k_dense_fwd, k_head, k_wgrad_all).  Their in-pipeline durations are
+        # measured live with HIP events recorded on the bench stream around every kernel of 256 further
+        # steps of the same chain (eager launches: an event cannot sit inside a graph node sequence).
+        n_prof = 256
+        pidx_h, psizes = synth.batch_plan(N_ROWS, BATCH, n_prof, seed=977)
+        pidx = torch.as_tensor(pidx_h).to(dev)
+        plr = synth.sgld_lr_table(total + n_prof, LR_UPPER, LR_LOWER, LR_GAMMA, total, n_prof)
+        plosses = torch.zeros(n_prof, device=dev)
         with torch.cuda.stream(stream):
-            plan.loss_grad(theta, x, yy, batch=BATCH, row_idx=row)      # fills the workspace (activations, deltas)
-            best = None
-            for kind, name in ((0, "k_dense_fwd[layer0]"), (2, "k_wgrad_all")):
-                plan.lib.pyz_bench_dense_kernel(plan.h, kind, 0, engine.ptr(theta), 1, engine.ptr(x), engine.ptr(row),
-                                                BATCH, engine.ptr(grad), 20, engine._stream())
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                engine.check(plan.lib.pyz_bench_dense_kernel(plan.h, kind, 0, engine.ptr(theta), 1, engine.ptr(x),
-                                                             engine.ptr(row), BATCH, engine.ptr(grad), iters,
-                                                             engine._stream()))
-                e1.record(stream)
-                e1.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / iters
-                if best is None or us > best[1]:
-                    best = (name, us)
-        # algorithmic FLOP per launch: forward of layer 0, or [dW; db] of both layers (321.1 + 4.1 MFLOP)
-        flop = 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1]
-        if best[0] == "k_wgrad_all":
-            flop += 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]
-        achieved = flop / (best[1] * 1e-6) / 1e12
+            plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes[:16], plr[:16], total, SEED + rank, plosses)   # warm
+            us = plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes, plr, total + 16, SEED + rank, plosses)
+        names = ["k_dense_fwd", "k_head", "k_wgrad_all"]
+        # An event record between two kernels costs queue time of its own (the instrumented step is
+        # slower than the timed region's).  The three kernels tile the step, so the per-record overhead is
+        # (sum of the instrumented durations - step time of the timed region) / 3; it is removed from each.
         step_us = dt / args.steps * 1e6
-        roof = {"bound": "mfma", "kernel": best[0], "kernel_us": round(best[1], 3), "flop_per_launch": flop,
+        raw_us = list(us)
+        overhead = max(0.0, (sum(us) - step_us) / 3.0)
+        us = [v - overhead for v in us]
+        k = int(np.argmax(us))
+        # algorithmic FLOP per launch: forward of layer 0 = 2 B (K+1) N; head = last layer forward
+        # + its data gradient; k_wgrad_all = [dW; db] of both layers
+        flops = [2.0 * BATCH * (DIMS[0] + 1) * DIMS[1],
+                 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2] + 2.0 * BATCH * DIMS[1] * DIMS[2],
+                 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1] + 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]]
+        achieved = flops[k] / (us[k] * 1e-6) / 1e12
+        roof = {"bound": "mfma", "kernel": names[k], "kernel_us": round(us[k], 3), "flop_per_launch": flops[k],
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(best[0]),
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(names[k]),
+                "kernels_us": {n: round(v, 3) for n, v in zip(names, us)},
+                "kernels_us_with_event_overhead": {n: round(v, 3) for n, v in zip(names, raw_us)},
                 "whole_step": {"flop": FLOP_PER_STEP, "bytes": BYTES_PER_STEP, "us": round(step_us, 3),
                                "tflops": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12, 3),
                                "frac_mfma": round(FLOP_PER_STEP / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),

@@ -116,6 +116,15 @@ int pyz_sgld_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, 
                  const float *h_lr, int n_steps, int64_t n0, int64_t slot0, uint64_t seed,
                  float *d_losses, int use_graph, void *stream);
 
+/* Measurement (bench.py roofline leg): n_steps eager SGLD steps, same arguments and effect as
+ * pyz_sgld_run, with HIP events recorded on `stream` around the kernels of every step.
+ * h_avg_us[3] = average in-pipeline duration in microseconds (launch gap included) of
+ * {hidden-layer forward kernel(s), k_head, data-gradient kernels + k_wgrad_all}. */
+int pyz_sgld_profile(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean,
+                     const float *d_x, const void *d_y, const int32_t *d_row_idx,
+                     const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
+                     int64_t slot0, uint64_t seed, float *d_losses, float *h_avg_us, void *stream);
+
 /* ---- B2-B4: BBB.step (BBB.py:128-201).  d_mu / d_rho are the variational
  * parameters (D each); eps ~ N(0,1) from Philox (seed, step) or d_eps.
  * Writes the sampled weights to d_w (D, used by the validation pass), the
