@@ -28,11 +28,13 @@ __device__ __forceinline__ double pyz_block_sum(double v, double *sm) {
   return s;
 }
 
-// sum `n` partials (fixed order) -- called by ONE thread
+// sum `n` partials in a fixed order -- called by ALL 64 lanes of one wave (lane l takes
+// part[l], part[l + 64], ...; then a shuffle tree); the total is valid in lane 0.
+// (A single thread walking the partials serialises n dependent memory round trips.)
 __device__ __forceinline__ double pyz_sum_partials(const double *part, int n) {
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += part[i];
-  return s;
+  for (int i = threadIdx.x & 63; i < n; i += 64) s += part[i];
+  return pyz_wave_sum(s);
 }
 
 __device__ __forceinline__ float pyz_softplus(float x) {
@@ -133,8 +135,9 @@ __global__ void k_loss_mse(LossArgs g) {
 
 // loss[p] = (sum of the row-loss partials) / batch
 __global__ void k_loss_finalize(const double *part, int nblk, const StepCtl *ctl, float *loss) {
-  const int p = blockIdx.x;
-  if (threadIdx.x == 0) loss[p] = (float)(pyz_sum_partials(part + p * nblk, nblk) / (double)ctl->batch);
+  const int p = blockIdx.x;   // one 64-lane wave per particle
+  const double tot = pyz_sum_partials(part + p * nblk, nblk);
+  if (threadIdx.x == 0) loss[p] = (float)(tot / (double)ctl->batch);
 }
 
 // ---------------------------------------------------------------- SGD / SGLD
@@ -144,7 +147,10 @@ __global__ void k_sgd_update(float *theta, const float *grad, long long D, const
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const float lr = ctl->lr;
   if (e < D) theta[e] = theta[e] - lr * grad[e];
-  if (e == 0) loss[0] = (float)(pyz_sum_partials(part, nblk) / (double)ctl->batch);
+  if (blockIdx.x == 0 && threadIdx.x < 64) {   // first wave of the launch
+    const double tot = pyz_sum_partials(part, nblk);
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)ctl->batch);
+  }
 }
 
 // SGLD.step (SGLD.py:64-93), fused over the flat vector:
@@ -195,10 +201,13 @@ __global__ void k_sgld_update(SgldArgs g) {
       }
     }
   }
-  if (t == 0) {
-    float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
-    lo[0] = (float)(pyz_sum_partials(g.part, g.nblk) / (double)g.ctl->batch);
-    if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const double tot = pyz_sum_partials(g.part, g.nblk);
+    if (threadIdx.x == 0) {
+      float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
+      lo[0] = (float)(tot / (double)g.ctl->batch);
+      if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
+    }
   }
 }
 
@@ -291,12 +300,16 @@ __global__ void k_bbb_update(BbbArgs g) {
       }
     }
   }
-  if (t == 0) {
-    const float loss = (float)(pyz_sum_partials(g.part_loss, g.nblk_loss) / (double)g.ctl->batch);
-    const float kl = (float)pyz_sum_partials(g.part_kl, g.nblk_kl);
-    g.cost[0] = loss + g.alpha * kl;
-    g.cost[1] = loss;
-    g.cost[2] = kl;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const double sl = pyz_sum_partials(g.part_loss, g.nblk_loss);
+    const double sk = pyz_sum_partials(g.part_kl, g.nblk_kl);
+    if (threadIdx.x == 0) {
+      const float loss = (float)(sl / (double)g.ctl->batch);
+      const float kl = (float)sk;
+      g.cost[0] = loss + g.alpha * kl;
+      g.cost[1] = loss;
+      g.cost[2] = kl;
+    }
   }
 }
 
@@ -401,10 +414,12 @@ __global__ void k_hmc_end_energy(HmcArgs g) {
 // energies[c*4 + {0,1}] = {U, K} from the partials and the mean loss (HMC.py:149-166)
 __global__ void k_hmc_energy_finalize(const double *part, int nblk, const float *loss, float n_train, float m,
                                       float *energies, int slot) {
-  const int c = blockIdx.x;
+  const int c = blockIdx.x;   // one 64-lane wave per chain
+  const double d0 = pyz_sum_partials(part + (c * 2 + 0) * nblk, nblk);
+  const double d1 = pyz_sum_partials(part + (c * 2 + 1) * nblk, nblk);
   if (threadIdx.x != 0) return;
-  const float slp = (float)pyz_sum_partials(part + (c * 2 + 0) * nblk, nblk);
-  const float sp2 = (float)pyz_sum_partials(part + (c * 2 + 1) * nblk, nblk);
+  const float slp = (float)d0;
+  const float sp2 = (float)d1;
   float U = 0.0f - slp;              // potential_energy -= reduce_sum(log_prob)
   U = U + loss[c] * n_train;         // += loss * cardinality
   const float K = (1.0f / (2.0f * m)) * sp2;
