@@ -724,12 +724,32 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   a.cost = d_cost;
   hipLaunchKernelGGL(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
   WgradArgs u{};
-  u.mode = PYZ_UPD_NONE;
-  u.grad = m->grad;
-  u.grad_pstride = m->D;
-  launch_loss_backward(m, d_w, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
-  a.nblk_loss = m->cur_nblk;
-  hipLaunchKernelGGL(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
+  if (can_fuse(m)) {  // the mu / rho update runs in the epilogue of the weight-gradient kernel
+    u.mode = PYZ_UPD_BBB;
+    u.theta = d_mu;
+    u.mean = d_rho;
+    u.sq_mean = d_w;
+    u.seed = seed;
+    u.unit_noise = d_eps;
+    u.alpha = alpha;
+    u.prior_mean = prior_mean;
+    u.prior_rho = prior_rho;
+    u.bbb_lr = lr;
+    u.pm_vec = d_prior_mean_vec;
+    u.pr_vec = d_prior_rho_vec;
+    u.bbb_step = (uint32_t)step;
+    u.part_kl = full(m)->x.part2;
+    u.nblk_kl = nblk_kl;
+    u.cost = d_cost;
+    launch_loss_backward(m, d_w, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  } else {
+    u.mode = PYZ_UPD_NONE;
+    u.grad = m->grad;
+    u.grad_pstride = m->D;
+    launch_loss_backward(m, d_w, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+    a.nblk_loss = m->cur_nblk;
+    hipLaunchKernelGGL(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
+  }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }

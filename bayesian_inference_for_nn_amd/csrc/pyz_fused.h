@@ -211,6 +211,7 @@ struct WgradLayer {
 #define PYZ_UPD_NONE 0  // write [dW; db] to grad
 #define PYZ_UPD_SGD 1   // SGD.py:66-69
 #define PYZ_UPD_SGLD 2  // SGLD.py:64-93
+#define PYZ_UPD_BBB 3   // BBB.py:152-201 (theta = mu, mean = rho, sq_mean = the sampled w; read only)
 
 struct WgradArgs {
   WgradLayer lay[PYZ_MAX_LAYERS];
@@ -222,7 +223,14 @@ struct WgradArgs {
   long long grad_pstride;
   float *theta, *mean, *sq_mean;
   uint64_t seed;
-  const float *unit_noise;
+  const float *unit_noise;    // SGLD: injected N(0,1); BBB: injected eps
+  // BBB only
+  float alpha, prior_mean, prior_rho, bbb_lr;
+  const float *pm_vec, *pr_vec;
+  uint32_t bbb_step;
+  const double *part_kl;
+  int nblk_kl;
+  float *cost;
   // duties of workgroup 0 at the end of the step: loss and the next step's scalars
   const double *part;
   int nblk;
@@ -287,6 +295,19 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
     }
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1 && g.mode == PYZ_UPD_BBB) {   // cost = loss + alpha (log q - log p)
+    double v = 0.0, k = 0.0;
+    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
+    for (int q = l; q < g.nblk_kl; q += 64) k += g.part_kl[q];
+    v = pyz_wave_sum(v);
+    k = pyz_wave_sum(k);
+    if (l == 0) {
+      const float loss = (float)(v / (double)batch), kl = (float)k;
+      g.cost[0] = loss + g.alpha * kl;
+      g.cost[1] = loss;
+      g.cost[2] = kl;
+    }
+  }
 
   // -- epilogue operands of this thread's elements, fetched before the reduction so that
   //    their latency (and the Philox arithmetic) hides behind the operand loads / MFMAs
@@ -309,7 +330,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
     ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
     th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
     if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
-    if (mode == PYZ_UPD_SGLD) {
+    if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) {
       mu0[q] = g.mean[ee[q]];
       sq0[q] = g.sq_mean[ee[q]];
       if (g.unit_noise) zz[q] = g.unit_noise[ee[q]];
@@ -351,10 +372,12 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   } else {
     pyz_wgrad_accumulate(acc, ap, dp, ly.lda, N, batch, s, se, h, is_w, is_b);
   }
-  if (mode == PYZ_UPD_SGLD && !g.unit_noise) {
+  if ((mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-      const float4 nq = pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2));
+      const float4 nq = mode == PYZ_UPD_SGLD
+                            ? pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2))
+                            : pyz_normal4(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)(ee[q] >> 2));
       const int k = (int)(ee[q] & 3);
       zz[q] = k == 0 ? nq.x : (k == 1 ? nq.y : (k == 2 ? nq.z : nq.w));
     }
@@ -387,6 +410,18 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       g.grad[p * g.grad_pstride + e] = gv[q];
     } else if (mode == PYZ_UPD_SGD) {
       g.theta[e] = th0[q] - lr * gv[q];
+    } else if (mode == PYZ_UPD_BBB) {
+      // th0 = mu, mu0 = rho, sq0 = the sampled w, zz = eps, gv = d loss / d w   (k_bbb_update's arithmetic)
+      const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
+      const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), isp2 = 1.0f / (sp * sp);
+      const float mu = th0[q], rho = mu0[q], wv = sq0[q];
+      const float sg = pyz_softplus(rho), sig = pyz_sigmoid(rho);
+      const float d = wv - mu, is2 = 1.0f / (sg * sg);
+      const float g_mu = g.alpha * d * is2;
+      const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
+      const float g_w = gv[q] + g.alpha * (-d * is2 + (wv - pmean) * isp2);
+      g.theta[e] = mu - g.bbb_lr * (g_mu + g_w);
+      g.mean[e] = rho - g.bbb_lr * (zz[q] * sig * g_w + g_rho);
     } else {
       const float fn = (float)nstep, fn1 = fn + 1.0f;
       const float noise = lr * zz[q];
