@@ -36,6 +36,7 @@ SIGNATURES = {
     "pyz_mlp_forward": (C.c_int, [_p, _p, C.c_int, _p, _p, C.c_int, _p, _p]),
     "pyz_mlp_loss_grad": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, _p, _p, _p]),
     "pyz_sgd_step": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, _f, _p, _p]),
+    "pyz_swag_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _i64, C.c_int, _p, _p]),
     "pyz_sgld_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _i64, _u64, _p, _p, _p]),
     "pyz_sgld_run": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _i64, _i64, _u64,
                                _p, C.c_int, _p]),

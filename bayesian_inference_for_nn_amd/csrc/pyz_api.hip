@@ -493,6 +493,41 @@ int pyz_sgd_step(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, 
   return PYZ_OK;
 }
 
+// ---------------------------------------------------------------- SWAG (survey 8f, rank 2)
+int pyz_swag_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, float *d_dev_row, const float *d_x,
+                  const void *d_y, const int32_t *d_row_idx, int batch, float lr, int64_t n, int update_moments,
+                  float *d_loss, void *stream) {
+  int rc = check_call(m, 1, batch);
+  if (rc) return rc;
+  if ((rc = check_loss_combo(m))) return rc;
+  if (!d_theta || !d_mean || !d_sq_mean || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
+  const bool fused = can_fuse(m);
+  if (!fused && (rc = need_grad(m, 1))) return rc;
+  hipStream_t st = as_stream(stream);
+  if ((rc = set_ctl(m, 0, batch, lr, n, 0, 0, st))) return rc;
+  WgradArgs u{};
+  if (fused) {
+    u.mode = PYZ_UPD_SWAG;
+    u.theta = d_theta;
+    u.mean = d_mean;
+    u.sq_mean = d_sq_mean;
+    u.dev_row = d_dev_row;
+    u.swag_update = update_moments ? 1 : 0;
+    u.loss = d_loss;
+  } else {
+    u.mode = PYZ_UPD_NONE;
+    u.grad = m->grad;
+    u.grad_pstride = m->D;
+  }
+  launch_loss_backward(m, d_theta, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  if (!fused)
+    hipLaunchKernelGGL(k_swag_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, d_mean, d_sq_mean, d_dev_row,
+                       m->grad, m->D, update_moments ? 1 : 0, m->ctl, m->part, m->cur_nblk, d_loss);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
 // ---------------------------------------------------------------- L2/L3
 static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,

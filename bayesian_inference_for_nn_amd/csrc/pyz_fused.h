@@ -212,6 +212,7 @@ struct WgradLayer {
 #define PYZ_UPD_SGD 1   // SGD.py:66-69
 #define PYZ_UPD_SGLD 2  // SGLD.py:64-93
 #define PYZ_UPD_BBB 3   // BBB.py:152-201 (theta = mu, mean = rho, sq_mean = the sampled w; read only)
+#define PYZ_UPD_SWAG 4  // SWAG.py:61-92 (SGD update; gated moments; one deviation row)
 
 struct WgradArgs {
   WgradLayer lay[PYZ_MAX_LAYERS];
@@ -224,6 +225,9 @@ struct WgradArgs {
   float *theta, *mean, *sq_mean;
   uint64_t seed;
   const float *unit_noise;    // SGLD: injected N(0,1); BBB: injected eps
+  // SWAG only: dev_row = the (D) row of the deviation matrix that receives theta - mean, or nullptr
+  float *dev_row;
+  int swag_update;            // moments / deviation updated at this step (n % frequency == 0)
   // BBB only
   float alpha, prior_mean, prior_rho, bbb_lr;
   const float *pm_vec, *pr_vec;
@@ -330,10 +334,10 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
     ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
     th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
     if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
-    if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) {
+    if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB || mode == PYZ_UPD_SWAG) {
       mu0[q] = g.mean[ee[q]];
       sq0[q] = g.sq_mean[ee[q]];
-      if (g.unit_noise) zz[q] = g.unit_noise[ee[q]];
+      if (g.unit_noise && mode != PYZ_UPD_SWAG) zz[q] = g.unit_noise[ee[q]];
     }
   }
 
@@ -410,6 +414,16 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       g.grad[p * g.grad_pstride + e] = gv[q];
     } else if (mode == PYZ_UPD_SGD) {
       g.theta[e] = th0[q] - lr * gv[q];
+    } else if (mode == PYZ_UPD_SWAG) {
+      const float th = th0[q] - lr * gv[q];
+      g.theta[e] = th;
+      if (g.swag_update) {
+        const float fn = (float)nstep, fn1 = fn + 1.0f;
+        const float mn = (mu0[q] * fn + th) / fn1;
+        g.mean[e] = mn;
+        g.sq_mean[e] = (sq0[q] * fn + th * th) / fn1;
+        if (g.dev_row) g.dev_row[e] = th - mn;
+      }
     } else if (mode == PYZ_UPD_BBB) {
       // th0 = mu, mu0 = rho, sq0 = the sampled w, zz = eps, gv = d loss / d w   (k_bbb_update's arithmetic)
       const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;

@@ -153,6 +153,29 @@ __global__ void k_sgd_update(float *theta, const float *grad, long long D, const
   }
 }
 
+// SWAG.step update for nets the fused path does not take (SWAG.py:61-92): SGD update, then (when
+// `update`) the running moments with count n and one deviation row.
+__global__ void k_swag_update(float *theta, float *mean, float *sq_mean, float *dev_row, const float *grad, long long D,
+                              int update, const StepCtl *ctl, const double *part, int nblk, float *loss) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float lr = ctl->lr;
+  if (e < D) {
+    const float th = theta[e] - lr * grad[e];
+    theta[e] = th;
+    if (update) {
+      const float fn = (float)ctl->n, fn1 = fn + 1.0f;
+      const float mn = (mean[e] * fn + th) / fn1;
+      mean[e] = mn;
+      sq_mean[e] = (sq_mean[e] * fn + th * th) / fn1;
+      if (dev_row) dev_row[e] = th - mn;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const double tot = pyz_sum_partials(part, nblk);
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)ctl->batch);
+  }
+}
+
 // SGLD.step (SGLD.py:64-93), fused over the flat vector:
 //   noise = lr * z;  theta += -lr * (grad + noise)
 //   mean <- (mean * n + theta) / (n + 1);  sq_mean <- (sq_mean * n + theta^2) / (n + 1)

@@ -143,6 +143,17 @@ class MLPPlan:
         check(self.lib.pyz_sgd_step(self.h, ptr(theta), ptr(x), ptr(y), ptr(row_idx), batch, float(lr), ptr(loss_out),
                                     _stream()))
 
+    def swag_step(self, theta, mean, sq_mean, dev_row, x, y, lr, n, update_moments, loss_out, batch=None, row_idx=None):
+        for t, nm in ((theta, "theta"), (mean, "mean"), (sq_mean, "sq_mean")):
+            _f32(t, (self.D,), nm)
+        if dev_row is not None:
+            _f32(dev_row, (self.D,), "dev_row")
+        batch = int(batch if batch is not None else (row_idx.numel() if row_idx is not None else x.shape[0]))
+        self._check_xy(x, y, row_idx, batch)
+        check(self.lib.pyz_swag_step(self.h, ptr(theta), ptr(mean), ptr(sq_mean), ptr(dev_row), ptr(x), ptr(y),
+                                     ptr(row_idx), batch, float(lr), int(n), 1 if update_moments else 0, ptr(loss_out),
+                                     _stream()))
+
     # ------------------------------------------------------------------ L2/L3
     def sgld_step(self, theta, mean, sq_mean, x, y, lr, n, seed, loss_out, batch=None, row_idx=None, unit_noise=None):
         for t, nm in ((theta, "theta"), (mean, "mean"), (sq_mean, "sq_mean")):

@@ -116,9 +116,10 @@ class BayesianModel:
     # ------------------------------------------------------------------ persistence
     @classmethod
     def load(cls, model_path: str, custom_distribution_register=None) -> "BayesianModel":
-        from ..distributions import Sampled
+        from ..distributions import MultivariateNormalDiagPlusLowRank, Sampled
         from ..distributions.tf import TensorflowProbabilityDistribution
-        register = {"Sampled": Sampled, "TensorflowProbabilityDistribution": TensorflowProbabilityDistribution}
+        register = {"Sampled": Sampled, "TensorflowProbabilityDistribution": TensorflowProbabilityDistribution,
+                    "MultivariateNormalDiagPlusLowRank": MultivariateNormalDiagPlusLowRank}
         register.update(custom_distribution_register or {})
         with open(os.path.join(model_path, "config.json"), "r") as f:
             bayesian_model = BayesianModel(f.read())

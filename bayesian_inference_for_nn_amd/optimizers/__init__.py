@@ -4,3 +4,4 @@ from .HMC import HMC
 from .SGLD import SGLD
 from .SGD import SGD
 from .SVGD import SVGD
+from .SWAG import SWAG

@@ -96,6 +96,14 @@ int pyz_mlp_loss_grad(pyz_mlp *mlp, const float *d_theta, int n_particles, const
 int pyz_sgd_step(pyz_mlp *mlp, float *d_theta, const float *d_x, const void *d_y,
                  const int32_t *d_row_idx, int batch, float lr, float *d_loss, void *stream);
 
+/* ---- SWAG.step (Pyesian/optimizers/SWAG.py:43-94; survey 8f rank 2): theta <- theta - lr * grad;
+ * when update_moments != 0 (n % frequency == 0): mean / sq_mean running moments with count n and
+ * d_dev_row (float32[D], one row of the k x D deviation matrix, may be NULL) <- theta - mean.
+ * d_loss receives the batch loss. */
+int pyz_swag_step(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, float *d_dev_row,
+                  const float *d_x, const void *d_y, const int32_t *d_row_idx, int batch, float lr,
+                  int64_t n, int update_moments, float *d_loss, void *stream);
+
 /* ---- L2/L3: SGLD.step (SGLD.py:54-95).  noise = lr * z, z ~ N(0,1) from the
  * library's Philox stream (seed, step n) or from d_unit_noise (float32[D]) when
  * given; theta += -lr * (grad + noise); mean/sq_mean running moments with

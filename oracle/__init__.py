@@ -22,4 +22,4 @@ every gradient (oracle/torch_eager.py), and (c) the documented semantics of
 the third-party ops listed in SURVEY.md Appendix A.
 """
 
-from . import mlp, philox, sgd, sgld, hmc, bbb, svgd, predict  # noqa: F401
+from . import mlp, philox, sgd, sgld, hmc, bbb, svgd, swag, predict  # noqa: F401

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from oracle import bbb, hmc, mlp, philox, predict, sgd, sgld, svgd  # noqa: E402
+from oracle import bbb, hmc, mlp, philox, predict, sgd, sgld, svgd, swag  # noqa: E402
 
 DIMS, ACTS = (6, 9, 4), ("relu", "softmax")
 
@@ -56,6 +56,11 @@ def main():
     W = (rng.normal(size=(4, D)) * 0.4).astype(np.float32)
     s, m = predict.predict(W, x, spec)
     out.update(pred_W=W, pred_samples=s, pred_mean=m)
+    # SWAG, 5 steps, k = 2, frequency 2 (moments at steps 0, 2, 4; the third update replaces column 1)
+    st = swag.SWAGState(theta, 2)
+    for _ in range(5):
+        swag.swag_step(st, x, y, spec, 0.05, 2)
+    out.update(swag_theta=st.theta, swag_mean=st.mean, swag_sq_mean=st.sq_mean, swag_dev=st.dev)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

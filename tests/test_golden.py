@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import bbb, hmc, mlp, philox, predict, sgd, sgld, svgd
+from oracle import bbb, hmc, mlp, philox, predict, sgd, sgld, svgd, swag
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.npz"))
 SPEC = mlp.MLPSpec(tuple(int(d) for d in G["dims"]), ("relu", "softmax"), "scce")
@@ -35,6 +35,11 @@ def test_oracle_reproduces_the_committed_vectors():
     np.testing.assert_allclose(st.particles, G["svgd_p"], rtol=1e-11)
     s, m = predict.predict(G["pred_W"], x, SPEC)
     np.testing.assert_allclose(m, G["pred_mean"], rtol=1e-12)
+    st = swag.SWAGState(theta, 2)
+    for _ in range(5):
+        swag.swag_step(st, x, y, SPEC, 0.05, 2)
+    np.testing.assert_allclose(st.mean, G["swag_mean"], rtol=1e-11)
+    np.testing.assert_allclose(st.dev, G["swag_dev"], rtol=1e-9, atol=1e-14)
 
 
 @pytest.mark.gpu
@@ -80,3 +85,10 @@ def test_hip_path_hits_the_committed_vectors(gpu_device):
     assert abs(float(l1) - G["svgd_loss"]) <= 1e-4 * abs(G["svgd_loss"])
     samples, mean = plan.predict(dev(G["pred_W"]), x)
     close(samples, G["pred_samples"]); close(mean, G["pred_mean"])
+    th, mean, sq, rows, cols = theta.clone(), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), \
+        torch.zeros((2, D), device="cuda"), 0
+    for s in range(5):
+        upd = s % 2 == 0
+        plan.swag_step(th, mean, sq, rows[min(cols, 1)] if upd else None, x, y, 0.05, s, upd, l1)
+        cols += 1 if (upd and cols < 2) else 0
+    close(th, G["swag_theta"]); close(mean, G["swag_mean"]); close(sq, G["swag_sq_mean"]); close(rows, G["swag_dev"])

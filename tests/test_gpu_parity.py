@@ -18,6 +18,7 @@ from oracle import predict as o_predict
 from oracle import sgd as o_sgd
 from oracle import sgld as o_sgld
 from oracle import svgd as o_svgd
+from oracle import swag as o_swag
 
 
 def close(gpu, ref, rel=1e-4, what=""):
@@ -184,6 +185,31 @@ def test_sgd_step_unfused_path(eng):
         rl, _ = o_sgd.sgd_step(st, x, y, spec, 0.05)
         close(loss, [rl], what="loss")
     close(th, st.theta, what="theta")
+
+
+# ------------------------------------------------------------------ SWAG
+@pytest.mark.parametrize("name", ["tiny_cls", "wide3", "wide_regression"])
+def test_swag_step_matches_oracle(eng, name):
+    """SGD update + gated moments + the deviation rows (append until k, then replace the last)."""
+    spec, n = SPECS[name]
+    x, y, theta = make(spec, n, seed=21)
+    D, k, freq = spec.n_params, 3, 2
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n)
+    st = o_swag.SWAGState(theta, k)
+    th, mean, sq = dev(theta), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    rows, n_cols, loss = torch.zeros((k, D), device="cuda"), 0, torch.zeros(1, device="cuda")
+    for s in range(11):
+        upd = s % freq == 0
+        col = min(n_cols, k - 1)
+        plan.swag_step(th, mean, sq, rows[col] if upd else None, dev(x), ydev(spec, y), 0.05, s, upd, loss)
+        n_cols += 1 if (upd and n_cols < k) else 0
+        rl = o_swag.swag_step(st, x, y, spec, 0.05, freq)
+        close(loss, [rl], what=f"loss {s}")
+    assert n_cols == st.dev.shape[0] == k
+    close(th, st.theta, what="theta")
+    close(mean, st.mean, what="mean")
+    close(sq, st.sq_mean, what="sq_mean")
+    close(rows, st.dev, what="deviation rows")
 
 
 # ------------------------------------------------------------------ SGLD

@@ -20,7 +20,7 @@ from bayesian_inference_for_nn_amd.datasets import Dataset
 from bayesian_inference_for_nn_amd.distributions import GaussianPrior
 from bayesian_inference_for_nn_amd.losses import MeanSquaredError, SparseCategoricalCrossentropy
 from bayesian_inference_for_nn_amd.nn import BayesianModel, model_from_json, sequential_json
-from bayesian_inference_for_nn_amd.optimizers import BBB, HMC, SGD, SGLD, SVGD
+from bayesian_inference_for_nn_amd.optimizers import BBB, HMC, SGD, SGLD, SVGD, SWAG
 from bayesian_inference_for_nn_amd.optimizers.hyperparameters import HyperParameters
 
 
@@ -233,3 +233,31 @@ def test_compat_standins_run_a_reference_style_driver():
         runpy.run_path(os.path.join(root, "examples", "hmc_classification_compat.py"), run_name="__main__")
     finally:
         sys.path.remove(os.path.join(root, "compat"))
+
+
+def test_swag_moons_posterior_and_store_load(tmp_path):
+    """SWAG from an SGD-pretrained model (the reference's SWAG usage): per-layer
+    MultivariateNormalDiagPlusLowRank posterior, store/load round trip, accuracy kept."""
+    from bayesian_inference_for_nn_amd.distributions import MultivariateNormalDiagPlusLowRank
+    ds = moons_dataset()
+    start = model_from_json(MOONS_JSON)
+    pre = SGD()
+    pre.compile(HyperParameters(lr=0.1, frequency=1), MOONS_JSON, ds, verbose=False, starting_model=start, seed=2)
+    pre.train(600)
+    opt = SWAG()
+    opt.compile(HyperParameters(lr=0.02, k=5, frequency=3, scale=1.0, batch_size=64), MOONS_JSON, ds, verbose=False,
+                starting_model=pre.result()._model, seed=3)
+    opt.train(60)
+    assert opt._n == 60 and opt._n_cols == 5
+    bm = opt.result()
+    assert len(bm._distributions) == 2 and all(isinstance(d, MultivariateNormalDiagPlusLowRank) for d in bm._distributions)
+    d0 = bm._distributions[0]
+    assert d0._D.shape == (2 * 16 + 16, 5) and np.all(d0._diag > -1e-6)
+    xt, yt = next(iter(ds.test_data.batch(ds.test_size)))
+    _, mean = bm.predict(xt, nb_samples=20)
+    acc = float(np.mean(np.argmax(mean, axis=1) == yt.numpy().ravel()))
+    assert acc > 0.8
+    bm.store(str(tmp_path / "swag"))
+    back = BayesianModel.load(str(tmp_path / "swag"))
+    assert [type(d).__name__ for d in back._distributions] == ["MultivariateNormalDiagPlusLowRank"] * 2
+    np.testing.assert_allclose(back._distributions[1]._D, bm._distributions[1]._D, rtol=1e-6)

@@ -219,3 +219,21 @@ def test_compat_tensorflow_standin_builds_keras_json():
     finally:
         sys.path.remove(os.path.join(root, "compat"))
         sys.modules.pop("tensorflow", None)
+
+
+def test_lowrank_plus_diag_distribution_sampling_and_round_trip(tmp_path):
+    """MultivariateNormalDiagPlusLowRank.py:31-41: mean + N(0, scale=diag) + D z sqrt(1/(2(k-1)))."""
+    from bayesian_inference_for_nn_amd.distributions import MultivariateNormalDiagPlusLowRank, tfd
+    rng = np.random.default_rng(5)
+    mean, diag, D = rng.normal(size=6), np.abs(rng.normal(size=6)) * 0.1, rng.normal(size=(6, 3))
+    dist = MultivariateNormalDiagPlusLowRank(mean, diag, D)
+    tfd.seed(4)
+    s = dist.sample_n(40000)
+    assert s.shape == (40000, 6) and dist.sample().shape == (6,)
+    np.testing.assert_allclose(s.mean(0), mean, atol=0.03)
+    cov = np.diag(diag.astype(np.float64) ** 2) + D @ D.T / (2 * (3 - 1))
+    np.testing.assert_allclose(np.cov(s.T), cov, atol=0.06)
+    dist.store(str(tmp_path))
+    back = MultivariateNormalDiagPlusLowRank.load(str(tmp_path))
+    np.testing.assert_allclose(back._D, dist._D)
+    np.testing.assert_allclose(back._diag, dist._diag)

@@ -292,3 +292,29 @@ def test_predict_mean_nan_to_zero_and_labels():
     np.testing.assert_allclose(mean, np.nan_to_num(outs).sum(0) / 4)
     assert predict.sampled_index([1, 3, 4], 1) == 0 and predict.sampled_index([1, 3, 4], 2) == 1
     assert predict.sampled_index([1, 3, 4], 4) == 2
+
+
+def test_swag_moments_are_running_averages_and_deviation_rule():
+    """frequency=1: mean / sq_mean are the plain averages of the iterates; the deviation matrix fills
+    to k columns and then only its last column is replaced (SWAG.py:84-89)."""
+    from oracle import swag
+    spec = mlp.MLPSpec((3, 4, 2), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(0)
+    x, y = rng.normal(size=(9, 3)), rng.integers(0, 2, size=9)
+    st = swag.SWAGState(rng.normal(size=spec.n_params) * 0.3, k=3)
+    thetas, firsts = [], None
+    for s in range(7):
+        swag.swag_step(st, x, y, spec, 0.1, 1)
+        thetas.append(st.theta.copy())
+        if s == 2:
+            firsts = st.dev[:2].copy()
+    np.testing.assert_allclose(st.mean, np.mean(thetas, 0), rtol=1e-12)
+    np.testing.assert_allclose(st.sq_mean, np.mean(np.square(thetas), 0), rtol=1e-12)
+    assert st.dev.shape == (3, spec.n_params)
+    np.testing.assert_array_equal(st.dev[:2], firsts)                    # kept forever
+    np.testing.assert_allclose(st.dev[2], st.theta - st.mean, rtol=1e-12)
+    mean, diag, D = swag.result_distribution(st, scale=2.0)
+    assert D.shape == (spec.n_params, 3) and np.all(diag > -1e-12)
+    np.testing.assert_allclose(D, st.dev.T, rtol=1e-12)                  # sqrt(scale/(k-1)) = 1
+    z1, z2 = rng.normal(size=spec.n_params), rng.normal(size=3)
+    np.testing.assert_allclose(swag.lowrank_sample(mean, diag, D, z1, z2), mean + diag * z1 + D @ z2 * 0.5, rtol=1e-12)
