@@ -295,7 +295,7 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
                           hipStream_t st) {
   if (can_fuse(m)) {
-    static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 0);  // 1: forward leaves a contiguous batch copy
+    static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 1);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
     hipEvent_t *ev = m->probe;  // measurement only (pyz_sgld_profile)
     if (ev) (void)hipEventRecord(ev[0], st);
@@ -380,6 +380,14 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     off += (long long)(m->dims[l] + 1) * m->dims[l + 1];
   }
   m->D = off;
+  {  // the kernels address operands with 32-bit byte offsets from per-layer bases (buffer descriptors)
+    long long widest = 0;
+    for (int l = 0; l <= n_layers; ++l) widest = std::max<long long>(widest, m->dims[l]);
+    if ((long long)max_batch * widest * 4 >= (1LL << 31) || off * 4 >= (1LL << 31)) {
+      delete m;
+      return pyz_fail(PYZ_E_INVALID, "max_batch x widest layer, or the parameter vector, exceeds 2 GiB");
+    }
+  }
   auto fail = [&](int rc) {
     pyz_mlp_destroy(m);
     return rc;

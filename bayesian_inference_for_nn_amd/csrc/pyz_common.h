@@ -33,7 +33,7 @@ struct StepCtl {
 // {s_memtime, s_memrealtime} at phase boundaries.  The shipped library has no stamps.
 #ifdef PYZ_STAMPS
 #define PYZ_STAMP_KERNELS 4
-#define PYZ_STAMP_BLOCKS 64
+#define PYZ_STAMP_BLOCKS 256
 #define PYZ_STAMP_WAVES 16
 #define PYZ_STAMP_SLOTS 8
 __device__ unsigned long long pyz_dbg_buf[PYZ_STAMP_KERNELS][PYZ_STAMP_BLOCKS][PYZ_STAMP_WAVES][PYZ_STAMP_SLOTS][2];
@@ -51,6 +51,12 @@ __device__ unsigned long long pyz_dbg_buf[PYZ_STAMP_KERNELS][PYZ_STAMP_BLOCKS][P
 #else
 #define PYZ_STAMP(kid, slot)
 #endif
+
+// wave index inside the workgroup as a SCALAR: threadIdx.x >> 6 is wave-uniform, but the compiler
+// only knows it once it has gone through readfirstlane; everything derived from it (the wave's slice of
+// the reduction, loop bounds, clamps) then lives in SGPRs and the loops branch on scalar compares
+// instead of exec-masked vector compares
+__device__ __forceinline__ int pyz_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---------------------------------------------------------------- host errors
 inline std::string &pyz_err_slot() {

@@ -57,7 +57,7 @@ __device__ __forceinline__ float pyz_grp8_sum(float v) {
 __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   extern __shared__ float lds[];
   PYZ_STAMP(1, 0);
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63, r = l & 31, h = l >> 5;
   float *red = lds, *zt = lds + S * 1024, *dt = zt + 32 * 33;
   double *lsum = reinterpret_cast<double *>(dt + 32 * 33);  // 4 doubles (8-byte aligned: S*4096 + 8448 bytes)
   const int batch = g.ctl->batch, p = blockIdx.y, m0 = blockIdx.x * 32;
@@ -75,15 +75,36 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   if (idx) yrow = idx[yrow];
   int ylab = 0;
   if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
+  // delta_{L-1} operands of this wave's tile (jt = w): the act' inputs and the W rows depend on nothing
+  // computed here, so they are fetched now and their latency hides behind phases 1 and 2
+  const int tiles_j = (K + 31) >> 5;
+  const int nsteps = (N + 1) >> 1;  // <= 16 (N <= 32)
+  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
+  const float *hp = g.hin + p * g.hin_pstride;
+  const bool pre = g.delta_prev && w < tiles_j && !g.gather_hin;
+  float hv0[16], bw0[16];
+  if (pre) {
+    const int j = min(w * 32 + r, K - 1);
+    const float *wp = wl + (long long)j * N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mm = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, batch - 1);
+      hv0[i] = hp[(long long)mm * K + j];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int kk = 2 * q + h;
+      bw0[q] = (q < nsteps) ? wp[kk < N ? kk : 0] : 0.0f;
+    }
+  }
   {
     const int m = min(m0 + r, batch - 1), n = min(r, N - 1);
     long long row = m;
     if (g.gather_hin && idx) row = idx[m];
     const float *ap = g.hin + p * g.hin_pstride + row * g.lda;
-    const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
     f32x16 acc = {0};
     PYZ_STAMP(1, 1);
-    pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h);
+    pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h);
     PYZ_STAMP(1, 2);
     float *my = red + w * 1024;
 #pragma unroll
@@ -159,34 +180,46 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   PYZ_STAMP(1, 4);
   if (!g.delta_prev) return;
   // ---- delta_{L-1} tile by tile: (delta_L [32 x N]) (W^T [N x 32]) * act'(h_in)
-  const int tiles_j = (K + 31) >> 5;
-  const int nsteps = (N + 1) >> 1;
-  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
-  const float *hp = g.hin + p * g.hin_pstride;
   float *op = g.delta_prev + p * g.prev_pstride;
   for (int jt = w; jt < tiles_j; jt += S) {
     const int j0 = jt * 32, jj = j0 + r, j = min(jj, K - 1);
     const float *wp = wl + (long long)j * N;
-    float hv[16];  // act' inputs, fetched with the W operands (one round trip, not 16)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int mm = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, batch - 1);
-      hv[i] = hp[(long long)mm * K + j];
-    }
+    float hv[16];
     f32x16 acc = {0};
-    pyz_steps1_all(
-        0, nsteps, acc,
-        [&](int s, float &a, float &b) {
-          const int kk = 2 * s + h;
-          const int kc = kk < N ? kk : 0;
-          a = dt[r * 33 + kc];
-          b = wp[kc];
-        },
-        [&](int s, float &a, float &b) {
-          const bool vk = 2 * s + h < N;
-          a = vk ? a : 0.0f;
-          b = vk ? b : 0.0f;
-        });
+    if (pre && jt == w) {  // operands already in registers
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hv[i] = hv0[i];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < nsteps) {
+          const int kk = 2 * q + h;
+          const bool vk = kk < N;
+          const float a = vk ? dt[r * 33 + kk] : 0.0f;
+          acc = pyz_mfma(a, vk ? bw0[q] : 0.0f, acc);
+        }
+      PYZ_STAMP(1, 6);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int mm = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, batch - 1);
+        long long row = mm;
+        if (g.gather_hin && idx) row = idx[mm];
+        hv[i] = hp[row * K + j];
+      }
+      pyz_steps1_all(
+          0, nsteps, acc,
+          [&](int s, float &a, float &b) {
+            const int kk = 2 * s + h;
+            const int kc = kk < N ? kk : 0;
+            a = dt[r * 33 + kc];
+            b = wp[kc];
+          },
+          [&](int s, float &a, float &b) {
+            const bool vk = 2 * s + h < N;
+            a = vk ? a : 0.0f;
+            b = vk ? b : 0.0f;
+          });
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int mm = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -246,22 +279,123 @@ struct WgradArgs {
   long long row_stride;
 };
 
-// contiguous (no gather) reduction over the batch rows, software pipelined
-__device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *ap, const float *dp, const int lda,
-                                                     const int N, const int batch, int s, const int se, const int h,
-                                                     const bool is_w, const bool is_b) {
+// ---------------------------------------------------------------- the optimizer updates (shared by the
+// epilogue of k_wgrad_all; kept apart from the tile code so that every mode is one readable block)
+struct PyzUpdOut {
+  float th, mu, sq, dev;
+  bool wr_mu, wr_sq, wr_dev;
+};
+
+// gv = d loss / d parameter e; th0 / mu0 / sq0 / zz = the state read before (see the modes above)
+__device__ __forceinline__ PyzUpdOut pyz_update_math(const WgradArgs &g, const int mode, const long long e, const float gv,
+                                                     const float th0, const float mu0, const float sq0, const float zz,
+                                                     const float lr, const long long nstep) {
+  PyzUpdOut o;
+  o.th = o.mu = o.sq = o.dev = 0.0f;
+  o.wr_mu = o.wr_sq = o.wr_dev = false;
+  if (mode == PYZ_UPD_SGD) {
+    o.th = th0 - lr * gv;
+  } else if (mode == PYZ_UPD_SWAG) {
+    const float th = th0 - lr * gv;
+    o.th = th;
+    if (g.swag_update) {
+      const float fn = (float)nstep, fn1 = fn + 1.0f;
+      o.mu = (mu0 * fn + th) / fn1;
+      o.sq = (sq0 * fn + th * th) / fn1;
+      o.dev = th - o.mu;
+      o.wr_mu = o.wr_sq = true;
+      o.wr_dev = g.dev_row != nullptr;
+    }
+  } else if (mode == PYZ_UPD_BBB) {
+    // th0 = mu, mu0 = rho, sq0 = the sampled w, zz = eps, gv = d loss / d w   (k_bbb_update's arithmetic)
+    const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
+    const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), isp2 = 1.0f / (sp * sp);
+    const float mu = th0, rho = mu0, wv = sq0;
+    const float sg = pyz_softplus(rho), sig = pyz_sigmoid(rho);
+    const float d = wv - mu, is2 = 1.0f / (sg * sg);
+    const float g_mu = g.alpha * d * is2;
+    const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
+    const float g_w = gv + g.alpha * (-d * is2 + (wv - pmean) * isp2);
+    o.th = mu - g.bbb_lr * (g_mu + g_w);
+    o.mu = rho - g.bbb_lr * (zz * sig * g_w + g_rho);
+    o.wr_mu = true;
+  } else if (mode == PYZ_UPD_SGLD) {
+    const float fn = (float)nstep, fn1 = fn + 1.0f;
+    const float noise = lr * zz;
+    const float th = th0 + (-lr) * (gv + noise);
+    o.th = th;
+    o.mu = (mu0 * fn + th) / fn1;
+    o.sq = (sq0 * fn + th * th) / fn1;
+    o.wr_mu = o.wr_sq = true;
+  }
+  return o;
+}
+
+__device__ __forceinline__ void pyz_update_store(const WgradArgs &g, const int mode, const long long e, const int p,
+                                                 const float gv, const PyzUpdOut &o) {
+  if (mode == PYZ_UPD_NONE) {
+    g.grad[p * g.grad_pstride + e] = gv;
+    return;
+  }
+  g.theta[e] = o.th;
+  if (o.wr_mu) g.mean[e] = o.mu;
+  if (o.wr_sq) g.sq_mean[e] = o.sq;
+  if (o.wr_dev) g.dev_row[e] = o.dev;
+}
+
+// duties of one spare wave per step that do not depend on the gradient: the loss of this step
+// (partials written by k_head), BBB's cost, and the next step's scalars
+__device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l) {
+  const int batch = g.ctl->batch;
+  if (g.loss) {
+    double v = 0.0;
+    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
+    v = pyz_wave_sum(v);
+    if (l == 0) {
+      float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
+      lo[0] = (float)(v / (double)batch);
+      if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
+    }
+  }
+  if (g.mode == PYZ_UPD_BBB) {   // cost = loss + alpha (log q - log p)
+    double v = 0.0, k = 0.0;
+    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
+    for (int q = l; q < g.nblk_kl; q += 64) k += g.part_kl[q];
+    v = pyz_wave_sum(v);
+    k = pyz_wave_sum(k);
+    if (l == 0) {
+      const float loss = (float)(v / (double)batch), kl = (float)k;
+      g.cost[0] = loss + g.alpha * kl;
+      g.cost[1] = loss;
+      g.cost[2] = kl;
+    }
+  }
+}
+
+// contiguous (no gather) reduction over the batch rows, software pipelined.  Operands come through
+// buffer descriptors built from wave-uniform bases: a step's address is a scalar row offset
+// (soffset) plus a per-lane constant (voffset), so the loop spends no vector ALU on addressing, and
+// the descriptor's byte count makes the row past an odd batch read as zero (no per-step row masks).
+// Requires batch * row bytes < 2^31 (checked when the plan is created).
+
+__device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *abase, const int ic, const float *dbase,
+                                                     const int n, const int lda, const int N, const int batch, int s,
+                                                     const int se, const int h, const bool is_w, const bool is_b) {
+  const float bconst = is_b ? 1.0f : 0.0f;
+  const unsigned a_lane = ((unsigned)h * (unsigned)lda + (unsigned)ic) * 4u;
+  const unsigned d_lane = ((unsigned)h * (unsigned)N + (unsigned)n) * 4u;
+  const unsigned a_row2 = 8u * (unsigned)lda, d_row2 = 8u * (unsigned)N;  // bytes per MFMA step (two rows)
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(abase), 0, (int)((unsigned)batch * (unsigned)lda * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dbase), 0, (int)((unsigned)batch * (unsigned)N * 4u), 0x00020000);
   pyz_steps1_all(
       s, se, acc,
       [&](int st, float &a, float &d) {
-        const int bc = min(2 * st + h, batch - 1);
-        a = ap[(long long)bc * lda];
-        d = dp[(long long)bc * N];
+        a = pyz_buf_load(ra, a_lane, (unsigned)PYZ_HOT(st, batch) * a_row2);
+        d = pyz_buf_load(rd, d_lane, (unsigned)PYZ_HOT(st, batch) * d_row2);
       },
-      [&](int st, float &a, float &d) {
-        const bool vb = 2 * st + h < batch;
-        a = vb ? (is_w ? a : (is_b ? 1.0f : 0.0f)) : 0.0f;
-        d = vb ? d : 0.0f;
-      });
+      [&](int, float &a, float &) { a = is_w ? a : bconst; });
 }
 
 // S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread)
@@ -270,7 +404,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   extern __shared__ float red[];
   PYZ_STAMP(2, 0);
   constexpr int EPT = 16 / S;  // tile elements per thread in the epilogue
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   int li = 0;
@@ -287,31 +421,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const long long nstep = g.ctl->n;
   const float lr = g.ctl->lr;
 
-  // -- duties of the step that do not depend on this kernel's work: the loss of this step
-  //    (partials written by k_head) and the next step's scalars; one spare wave, at the start
-  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1 && g.loss) {
-    double v = 0.0;
-    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
-    v = pyz_wave_sum(v);
-    if (l == 0) {
-      float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
-      lo[0] = (float)(v / (double)batch);
-      if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
-    }
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1 && g.mode == PYZ_UPD_BBB) {   // cost = loss + alpha (log q - log p)
-    double v = 0.0, k = 0.0;
-    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
-    for (int q = l; q < g.nblk_kl; q += 64) k += g.part_kl[q];
-    v = pyz_wave_sum(v);
-    k = pyz_wave_sum(k);
-    if (l == 0) {
-      const float loss = (float)(v / (double)batch), kl = (float)k;
-      g.cost[0] = loss + g.alpha * kl;
-      g.cost[1] = loss;
-      g.cost[2] = kl;
-    }
-  }
+  // -- duties of the step that do not depend on this kernel's work; one spare wave, at the start
+  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1) pyz_step_duties(g, l);
 
   // -- epilogue operands of this thread's elements, fetched before the reduction so that
   //    their latency (and the Philox arithmetic) hides behind the operand loads / MFMAs
@@ -362,8 +473,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       pyz_steps1_all(
           s0, min(s0 + 32, se), acc,
           [&](int st, float &a, float &d) {
-            const int bc = min(2 * st + h, batch - 1);
-            const long long row = __shfl(idxv, 2 * (st - s0) + h, 64);
+            const int bc = PYZ_HOT(min(2 * st + h, batch - 1), batch);
+            const long long row = PYZ_HOT(__shfl(idxv, 2 * (st - s0) + h, 64), batch);
             a = ap[row * lda];
             d = dp[(long long)bc * N];
           },
@@ -374,7 +485,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
           });
     }
   } else {
-    pyz_wgrad_accumulate(acc, ap, dp, ly.lda, N, batch, s, se, h, is_w, is_b);
+    pyz_wgrad_accumulate(acc, ly.in + p * ly.in_pstride, ic, ly.delta + p * ly.delta_pstride, n, ly.lda, N, batch, s, se, h,
+                         is_w, is_b);
   }
   if ((mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
 #pragma unroll
@@ -409,41 +521,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     if (!ev[q]) continue;
-    const long long e = ee[q];
-    if (mode == PYZ_UPD_NONE) {
-      g.grad[p * g.grad_pstride + e] = gv[q];
-    } else if (mode == PYZ_UPD_SGD) {
-      g.theta[e] = th0[q] - lr * gv[q];
-    } else if (mode == PYZ_UPD_SWAG) {
-      const float th = th0[q] - lr * gv[q];
-      g.theta[e] = th;
-      if (g.swag_update) {
-        const float fn = (float)nstep, fn1 = fn + 1.0f;
-        const float mn = (mu0[q] * fn + th) / fn1;
-        g.mean[e] = mn;
-        g.sq_mean[e] = (sq0[q] * fn + th * th) / fn1;
-        if (g.dev_row) g.dev_row[e] = th - mn;
-      }
-    } else if (mode == PYZ_UPD_BBB) {
-      // th0 = mu, mu0 = rho, sq0 = the sampled w, zz = eps, gv = d loss / d w   (k_bbb_update's arithmetic)
-      const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
-      const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), isp2 = 1.0f / (sp * sp);
-      const float mu = th0[q], rho = mu0[q], wv = sq0[q];
-      const float sg = pyz_softplus(rho), sig = pyz_sigmoid(rho);
-      const float d = wv - mu, is2 = 1.0f / (sg * sg);
-      const float g_mu = g.alpha * d * is2;
-      const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
-      const float g_w = gv[q] + g.alpha * (-d * is2 + (wv - pmean) * isp2);
-      g.theta[e] = mu - g.bbb_lr * (g_mu + g_w);
-      g.mean[e] = rho - g.bbb_lr * (zz[q] * sig * g_w + g_rho);
-    } else {
-      const float fn = (float)nstep, fn1 = fn + 1.0f;
-      const float noise = lr * zz[q];
-      const float th = th0[q] + (-lr) * (gv[q] + noise);
-      g.theta[e] = th;
-      g.mean[e] = (mu0[q] * fn + th) / fn1;
-      g.sq_mean[e] = (sq0[q] * fn + th * th) / fn1;
-    }
+    pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q], zz[q], lr, nstep));
   }
   PYZ_STAMP(2, 3);
 }

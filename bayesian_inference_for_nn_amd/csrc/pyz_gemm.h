@@ -57,8 +57,21 @@ __device__ __forceinline__ int pyz_xcd_remap(const int bid, const int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + local;
 }
 
+// diagnostic build -DPYZ_EXP_HOT: every operand load of the reduction loops reads row / k index 0
+// (same instruction stream, all loads hit L1) -- separates memory time from issue time
+#ifdef PYZ_EXP_HOT
+#define PYZ_HOT(v, batch) ((v) & ((batch) < 0 ? -1 : 0))
+#else
+#define PYZ_HOT(v, batch) (v)
+#endif
+
 __device__ __forceinline__ f32x16 pyz_mfma(float a, float b, f32x16 c) {
+#ifdef PYZ_EXP_NOMFMA   // diagnostic build: keep the operands alive with one VALU op instead of the MFMA
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ float pyz_act(float z, int act) {
@@ -86,7 +99,7 @@ __device__ __forceinline__ float pyz_act_grad(float h, int act) {
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 template <class F>
 __device__ __forceinline__ void pyz_tile_epilogue(const f32x16 &acc, float *red, F store) {
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   if (S == 1) {
 #pragma unroll
@@ -202,42 +215,55 @@ __device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc,
 
 // ---------------------------------------------------------------- forward
 // acc += sum_k A[k] * W[k][n] (+ bias via the augmented row), this wave's slice of K.
-// ap = this lane's input row, wp = &W[0][n] of this lane's output column.
-// gp (optional) = this lane's row of the gathered-batch copy: the A values are stored
-// there once they have arrived (at MFMA time, so the store never stalls the load phase).
-__device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap, const float *wp, const int K,
+// ap = this lane's input row; wl = the layer's [W; b] block (wave-uniform), n = this lane's output
+// column: the W operands come through a buffer descriptor (scalar k offset + per-lane constant, no
+// vector ALU per load).  gp (optional) = this lane's row of the gathered-batch copy: the A values
+// are stored there once they have arrived (at MFMA time, so the store never stalls the load
+// phase); the n-tiles of a row block share that copy, tile `copy_rem` of `copy_mod` stores the
+// chunks congruent to it.
+__device__ __forceinline__ float pyz_buf_load(const __amdgpu_buffer_rsrc_t rsrc, const unsigned voff, const unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap, const float *wl, const int n, const int K,
                                                    const int N, const int vec, const int w, const int S, const int h,
-                                                   float *gp = nullptr) {
-  const float bias = wp[(long long)K * N];  // issued first, consumed last
+                                                   float *gp = nullptr, const int copy_mod = 1, const int copy_rem = 0) {
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (int)((unsigned)(K + 1) * (unsigned)N * 4u), 0x00020000);
+  const unsigned n4 = 4u * (unsigned)n, N4 = 4u * (unsigned)N;
+  const float bias = pyz_buf_load(rw, n4, (unsigned)K * N4);  // issued first, consumed last
   // The S waves of a workgroup take INTERLEAVED 8-wide chunks of K (wave w: chunks w, w+S, ...):
   // at any moment the workgroup reads S adjacent chunks = a few whole 128-B lines per input row,
   // which stay in the 32 KiB L1 and are shared by the waves.  Contiguous per-wave K ranges put
   // S x 32 different lines in flight (more than the L1 holds) and refetch every line per 16-B piece.
   const int c8 = vec ? (K >> 3) : 0;
+  const unsigned v0 = (4u * h) * N4 + n4, v1 = v0 + N4, v2 = v1 + N4, v3 = v2 + N4;
   pyz_steps4_all(
       0, (c8 - w + S - 1) / S, acc,
       [&](int u, float4 &a4, float4 &b4) {
-        const int k = 8 * (w + S * u) + 4 * h;
-        a4 = *reinterpret_cast<const float4 *>(ap + k);
-        const float *bp = wp + (long long)k * N;
-        b4 = make_float4(bp[0], bp[N], bp[2 * (long long)N], bp[3 * (long long)N]);
+        const int c = PYZ_HOT(w + S * u, K);
+        a4 = *reinterpret_cast<const float4 *>(ap + 8 * c + 4 * h);
+        const unsigned so = 8u * (unsigned)c * N4;
+        b4 = make_float4(pyz_buf_load(rw, v0, so), pyz_buf_load(rw, v1, so), pyz_buf_load(rw, v2, so), pyz_buf_load(rw, v3, so));
       },
       [&](int u, const float4 &a4) {
-        if (gp) *reinterpret_cast<float4 *>(gp + 8 * (w + S * u) + 4 * h) = a4;
+        const int c = w + S * u;
+        if (gp && c % copy_mod == copy_rem) *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
       });
   const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
+  const unsigned vt = (unsigned)h * N4 + n4;
   pyz_steps1_all(
       0, (steps - w + S - 1) / S, acc,
       [&](int u, float &a, float &b) {
-        const int kk = t0 + 2 * (w + S * u) + h;
-        const int kc = kk < K ? kk : 0;
-        a = ap[kc];
-        b = wp[(long long)kc * N];
+        const int kb = t0 + 2 * (w + S * u);
+        const int kk = kb + h;
+        a = ap[kk < K ? kk : 0];
+        b = pyz_buf_load(rw, vt, (unsigned)kb * N4);   // row K (the bias) is inside the block; masked below
       },
       [&](int u, float &a, float &b) {
         const int kk = t0 + 2 * (w + S * u) + h;
         const bool vk = kk < K;
-        if (gp && vk) gp[kk] = a;
+        if (gp && vk && copy_rem == 0) gp[kk] = a;
         a = vk ? a : 0.0f;
         b = vk ? b : 0.0f;
       });
@@ -250,7 +276,7 @@ __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap,
 __global__ void k_dense_fwd(DenseArgs g) {
   extern __shared__ float red[];
   PYZ_STAMP(0, 0);
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int batch = g.ctl->batch;
   const int tiles_n = (g.N + 31) >> 5;
@@ -263,11 +289,11 @@ __global__ void k_dense_fwd(DenseArgs g) {
   long long row = m;
   if (g.row_idx) row = g.row_idx[g.ctl->row_off + m];
   const float *ap = g.in + p * g.in_pstride + row * g.lda;
-  const float *wp = g.theta + p * g.theta_pstride + g.w_off + n;
+  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
   f32x16 acc = {0};
   PYZ_STAMP(0, 1);
-  float *gp = (g.gather_out && n0 == 0 && p == 0) ? g.gather_out + (long long)m * K : nullptr;
-  pyz_fwd_accumulate(acc, ap, wp, K, N, g.vec, w, S, h, gp);
+  float *gp = (g.gather_out && p == 0) ? g.gather_out + (long long)m * K : nullptr;
+  pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h, gp, tiles_n, tile % tiles_n);
   PYZ_STAMP(0, 2);
   float *op = g.out + p * g.out_pstride;
   const int act = g.act;
@@ -283,7 +309,7 @@ __global__ void k_dense_fwd(DenseArgs g) {
 // `in` = delta (row stride N), `aux` = previous layer's output (row stride K).
 __global__ void k_dense_bwd_data(DenseArgs g) {
   extern __shared__ float red[];
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int batch = g.ctl->batch;
   const int K = g.K, N = g.N;
@@ -372,7 +398,7 @@ __device__ __forceinline__ void pyz_wgrad_steps(int &s, const int se, f32x16 &ac
 
 __global__ void k_dense_bwd_weight(DenseArgs g) {
   extern __shared__ float red[];
-  const int S = blockDim.x >> 6, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int batch = g.ctl->batch;
   const int K = g.K, N = g.N;

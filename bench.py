@@ -189,19 +189,20 @@ def main():
             plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes[:16], plr[:16], total, SEED + rank, plosses)   # warm
             us = plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes, plr, total + 16, SEED + rank, plosses)
         names = ["k_dense_fwd", "k_head", "k_wgrad_all"]
+        us = list(us)
         # An event record between two kernels costs queue time of its own (the instrumented step is
-        # slower than the timed region's).  The three kernels tile the step, so the per-record overhead is
-        # (sum of the instrumented durations - step time of the timed region) / 3; it is removed from each.
+        # slower than the timed region's).  The kernels tile the step, so the per-record overhead is
+        # (sum of the instrumented durations - step time of the timed region) / kernels; it is removed from each.
         step_us = dt / args.steps * 1e6
         raw_us = list(us)
-        overhead = max(0.0, (sum(us) - step_us) / 3.0)
+        overhead = max(0.0, (sum(us) - step_us) / len(us))
         us = [v - overhead for v in us]
-        k = int(np.argmax(us))
         # algorithmic FLOP per launch: forward of layer 0 = 2 B (K+1) N; head = last layer forward
         # + its data gradient; k_wgrad_all = [dW; db] of both layers
         flops = [2.0 * BATCH * (DIMS[0] + 1) * DIMS[1],
                  2.0 * BATCH * (DIMS[1] + 1) * DIMS[2] + 2.0 * BATCH * DIMS[1] * DIMS[2],
                  2.0 * BATCH * (DIMS[0] + 1) * DIMS[1] + 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]]
+        k = int(np.argmax(us))
         achieved = flops[k] / (us[k] * 1e-6) / 1e12
         roof = {"bound": "mfma", "kernel": names[k], "kernel_us": round(us[k], 3), "flop_per_launch": flops[k],
                 "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -34,13 +34,24 @@ with torch.cuda.stream(st):
     for rep in range(3):
         plan.sgld_run(theta, mean, sq, x, y, idx, sizes, lrs, 0, 1, losses, use_graph=True)
 st.synchronize()
-K, B, W, S = 4, 64, 16, 8
+K, B, W, S = 4, 256, 16, 8
 buf = (C.c_uint64 * (K * B * W * S * 2))()
 _lib.check(_lib.load().pyz_debug_stamps(buf, K * B * W * S * 2))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)
-names = {0: ("k_dense_fwd", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "end")], 64, 16),
-         1: ("k_head", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "lds combined"), (4, "loss rows done"), (5, "end")], 32, 8),
-         2: ("k_wgrad_all", [(0, "start"), (1, "addr+prefetch issued"), (2, "accumulate done"), (4, "tile reduced"), (3, "end")], 64, 16)}
+names = {0: ("k_dense_fwd", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "end")], 224, 16),
+         1: ("k_head", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "lds combined"), (4, "loss rows done"), (6, "delta_prev mfma issued"), (5, "end")], 32, 8),
+         2: ("k_wgrad_all", [(0, "start"), (1, "addr+prefetch issued"), (2, "accumulate done"), (4, "tile reduced"), (3, "end")], 182, 16)}
+# global timeline of the last recorded step (s_memrealtime is one 100 MHz counter for the chip)
+g0 = None
+for k, (nm, slots, nb, nw) in names.items():
+    tt = a[k, :nb, :nw, :, 1] * 10.0
+    used = tt[:, :, 0] > 0
+    st = np.where(used, tt[:, :, 0], np.inf).min(axis=1)
+    en = np.where(used, tt[:, :, slots[-1][0]], 0).max(axis=1)
+    if g0 is None:
+        g0 = st.min()
+    print(f"## {nm}: first wg start {st.min() - g0:7.0f}  last wg start {st.max() - g0:7.0f}  first wg end {en.min() - g0:7.0f}  "
+          f"last wg end {en.max() - g0:7.0f}  (ns since the first forward workgroup started; waves/wg {used.sum(axis=1).max()})")
 for k, (nm, slots, nb, nw) in names.items():
     t = a[k, :nb, :nw, :, 1] * 10.0          # ns, [block, wave, slot]
     cyc = a[k, :nb, :nw, :, 0]
