@@ -218,8 +218,26 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   g.last_pstride = (long long)m->max_batch * g.N;
   g.prev_pstride = (long long)m->max_batch * g.K;
   g.part = m->part;
-  g.nblk = cdiv(grid_batch, 32);
   g.ctl = ctl;
+  // one wave per batch row when the lane-resident operands fit (UT units x NP classes per lane)
+  static const int rows_on = pyz_env_int("PYZ_HEAD_ROWS", 1);
+  const int UT = g.K <= 64 ? 1 : g.K <= 256 ? 4 : g.K <= 512 ? 8 : g.K <= 1024 ? 16 : 0;
+  const int NP = g.N <= 4 ? 4 : g.N <= 8 ? 8 : g.N <= 12 ? 12 : g.N <= 16 ? 16 : g.N <= 24 ? 24 : 32;
+  if (rows_on && UT && UT * NP <= 128) {
+    g.nblk = grid_batch;  // one loss partial per row
+    m->cur_nblk = g.nblk;
+    const dim3 grid((unsigned)cdiv(grid_batch, 4), P), block(256);
+#define PYZ_HEAD_ROWS_CASE(U, C) \
+  if (UT == U && NP == C) { hipLaunchKernelGGL((k_head_rows<U, C>), grid, block, 0, st, g); return; }
+    PYZ_HEAD_ROWS_CASE(1, 4) PYZ_HEAD_ROWS_CASE(1, 8) PYZ_HEAD_ROWS_CASE(1, 12) PYZ_HEAD_ROWS_CASE(1, 16)
+    PYZ_HEAD_ROWS_CASE(1, 24) PYZ_HEAD_ROWS_CASE(1, 32)
+    PYZ_HEAD_ROWS_CASE(4, 4) PYZ_HEAD_ROWS_CASE(4, 8) PYZ_HEAD_ROWS_CASE(4, 12) PYZ_HEAD_ROWS_CASE(4, 16)
+    PYZ_HEAD_ROWS_CASE(4, 24) PYZ_HEAD_ROWS_CASE(4, 32)
+    PYZ_HEAD_ROWS_CASE(8, 4) PYZ_HEAD_ROWS_CASE(8, 8) PYZ_HEAD_ROWS_CASE(8, 12) PYZ_HEAD_ROWS_CASE(8, 16)
+    PYZ_HEAD_ROWS_CASE(16, 4) PYZ_HEAD_ROWS_CASE(16, 8)
+#undef PYZ_HEAD_ROWS_CASE
+  }
+  g.nblk = cdiv(grid_batch, 32);
   m->cur_nblk = g.nblk;
   static const int head_waves = pyz_env_int("PYZ_HEAD_WAVES", 8) >= 8 ? 8 : 4;
   hipLaunchKernelGGL(k_head, dim3(g.nblk, P), dim3(64 * head_waves), head_waves * 4096 + 2 * 32 * 33 * 4 + 64, st, g);
@@ -279,8 +297,9 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   a.ctl = ctl;
   a.part = m->part;
   a.nblk = m->cur_nblk;
+  a.tiles = tiles;
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
-  const dim3 grid((unsigned)tiles, P);
+  const dim3 grid((unsigned)tiles + 1, P);  // + the duties workgroup
   switch (S) {
     case 1: hipLaunchKernelGGL(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;
@@ -409,7 +428,7 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   if (hipMalloc((void **)&m->scal, scal) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "scalar allocation failed"));
   m->ws_bytes += scal;
   {
-    const int rc = need_part(m, (size_t)max_particles * cdiv(max_batch, 32) + 8);
+    const int rc = need_part(m, (size_t)max_particles * max_batch + 8);  // up to one loss partial per row (k_head_rows)
     if (rc != PYZ_OK) return fail(rc);
   }
   *out = m;

@@ -229,6 +229,132 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   PYZ_STAMP(1, 5);
 }
 
+// ---------------------------------------------------------------- head, one wave per batch row
+// The last layer of these models is narrow (N <= 32 classes / outputs) and its input a few hundred
+// wide: 32 rows x K x N per workgroup is too little for the MFMA path above to amortise its LDS
+// combines and barriers (k_head: 7.7 us in-kernel on 32 CUs for the 784->200->10 step).  Here every
+// WAVE owns ONE batch row and the grid covers the whole chip (batch/4 workgroups of 4 waves):
+// lane l holds hidden units l, l+64, ... (UT of them) and their W rows in registers, so
+//   z      = sum over the lane's units, then a butterfly sum over the 64 lanes (fixed order),
+//   loss row, delta_L           every lane redundantly (N <= 32 values),
+//   delta_{L-1}[u] = act'(h[u]) * sum_c delta_L[c] W[u][c]   for the lane's own units,
+// with no LDS, no barrier and coalesced row loads / stores.  NP = padded class count.
+template <int UT, int NP>
+__global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
+  PYZ_STAMP(1, 0);
+  const int w = pyz_wave_id(), l = threadIdx.x & 63;
+  const int batch = g.ctl->batch, p = blockIdx.y;
+  const int m = blockIdx.x * 4 + w;  // this wave's batch row (scalar)
+  if (m >= batch) {
+    if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
+    return;
+  }
+  const int K = g.K, N = g.N;
+  long long yrow = m;
+  if (g.row_idx) yrow = g.row_idx[g.ctl->row_off + m];
+  const float *hp = g.hin + p * g.hin_pstride + (g.gather_hin ? yrow : (long long)m) * g.lda;
+  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
+  // Operands through buffer descriptors: per-lane unit offset (voffset) + scalar class offset.  Units
+  // past K and classes past N read as zero (offsets beyond the descriptors' byte counts), so the
+  // class loops below are straight-line code over the NP padded classes: no per-class branches
+  // (conditional writes into the register arrays would turn them into whole-vector copies).
+  const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (K + 1) * N * 4, 0x00020000);
+  constexpr unsigned OOB = 0x7FFFFF00u;
+  float hv[UT], wv[UT][NP], z[NP];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+    const int u = l + 64 * t;
+    hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
+    const unsigned wo = u < K ? 4u * (unsigned)u * (unsigned)N : OOB;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) wv[t][c] = pyz_buf_load(rw, wo, c < N ? 4u * (unsigned)c : OOB);
+  }
+  const float bias_mine = pyz_buf_load(rw, l < N ? 4u * (unsigned)l : OOB, 4u * (unsigned)K * (unsigned)N);  // lane c: b[c]
+  int ylab = 0;
+  if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
+  PYZ_STAMP(1, 1);
+  // ---- z[c] = sum_u h[u] W[u][c] + b[c]: the lane's units, then a butterfly over the lanes
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    float a = 0.0f;
+#pragma unroll
+    for (int t = 0; t < UT; ++t) a = fmaf(hv[t], wv[t][c], a);
+    z[c] = a;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c) z[c] += __shfl_xor(z[c], o, 64);
+  }
+#pragma unroll
+  for (int c = 0; c < NP; ++c) z[c] += __shfl(bias_mine, c, 64);
+  PYZ_STAMP(1, 2);
+  // ---- loss row and delta_L (every lane holds all N values; padded classes carry zeros)
+  float d2[NP], outv[NP], lm;
+  if (g.loss == PYZ_LOSS_SCCE) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) mx = fmaxf(mx, c < N ? z[c] : -3.0e38f);
+    float ex[NP], se = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      ex[c] = c < N ? expf(z[c] - mx) : 0.0f;
+      se += ex[c];
+    }
+    const float lse = mx + logf(se);
+    float zy = __builtin_nanf("");
+    const float inv = 1.0f / (float)batch, rse = 1.0f / se;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      zy = (c == ylab && c < N) ? z[c] : zy;
+      d2[c] = (ex[c] * rse - ((c == ylab && c < N) ? 1.0f : 0.0f)) * inv;  // softmax - onehot, over the batch mean
+      outv[c] = z[c];
+    }
+    lm = lse - zy;
+  } else {
+    const float *y = reinterpret_cast<const float *>(g.y) + yrow * N;
+    const float sc = 2.0f / ((float)batch * (float)N);
+    const int act = g.act_last;
+    float a = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      const float o = pyz_act(z[c], act);
+      const float e = o - y[min(c, N - 1)];
+      a += c < N ? e * e : 0.0f;
+      d2[c] = c < N ? sc * e * pyz_act_grad(o, act) : 0.0f;
+      outv[c] = o;
+    }
+    lm = a / (float)N;
+  }
+  PYZ_STAMP(1, 3);
+  // lane c stores column c of the row
+  float my_d = 0.0f, my_o = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    my_d = (l == c) ? d2[c] : my_d;
+    my_o = (l == c) ? outv[c] : my_o;
+  }
+  if (l < N) {
+    if (g.out_last) g.out_last[p * g.last_pstride + (long long)m * N + l] = my_o;
+    if (g.delta_last) g.delta_last[p * g.last_pstride + (long long)m * N + l] = my_d;
+  }
+  if (l == 0) g.part[p * g.nblk + m] = (double)lm;
+  PYZ_STAMP(1, 4);
+  if (!g.delta_prev) return;
+  float *op = g.delta_prev + p * g.prev_pstride + (long long)m * K;
+  const int actp = g.act_prev;
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+    const int u = l + 64 * t;
+    float a = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) a = fmaf(d2[c], wv[t][c], a);
+    if (u < K) op[u] = a * pyz_act_grad(hv[t], actp);
+  }
+  PYZ_STAMP(1, 5);
+}
+
 // ---------------------------------------------------------------- all weight gradients + update
 struct WgradLayer {
   const float *in;            // layer input: data x (layer 0) or act[l-1]
@@ -250,6 +376,7 @@ struct WgradLayer {
 struct WgradArgs {
   WgradLayer lay[PYZ_MAX_LAYERS];
   int L;
+  int tiles;                  // tiles of all layers; the launch has one more workgroup, for the step duties
   const int32_t *row_idx;
   const StepCtl *ctl;
   int mode;
@@ -348,9 +475,7 @@ __device__ __forceinline__ void pyz_update_store(const WgradArgs &g, const int m
 __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l) {
   const int batch = g.ctl->batch;
   if (g.loss) {
-    double v = 0.0;
-    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
-    v = pyz_wave_sum(v);
+    const double v = pyz_sum_partials(g.part, g.nblk);
     if (l == 0) {
       float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
       lo[0] = (float)(v / (double)batch);
@@ -358,11 +483,7 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
     }
   }
   if (g.mode == PYZ_UPD_BBB) {   // cost = loss + alpha (log q - log p)
-    double v = 0.0, k = 0.0;
-    for (int q = l; q < g.nblk; q += 64) v += g.part[q];
-    for (int q = l; q < g.nblk_kl; q += 64) k += g.part_kl[q];
-    v = pyz_wave_sum(v);
-    k = pyz_wave_sum(k);
+    const double v = pyz_sum_partials(g.part, g.nblk), k = pyz_sum_partials(g.part_kl, g.nblk_kl);
     if (l == 0) {
       const float loss = (float)(v / (double)batch), kl = (float)k;
       g.cost[0] = loss + g.alpha * kl;
@@ -406,7 +527,13 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   constexpr int EPT = 16 / S;  // tile elements per thread in the epilogue
   const int w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
-  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
+  // workgroup `tiles` (the last id) owns no tile: its first wave does the duties of the step that do
+  // not depend on the gradient, off the critical path of the tile workgroups
+  if (blockIdx.x == (unsigned)g.tiles) {
+    if (blockIdx.y == 0 && w == 0) pyz_step_duties(g, l);
+    return;
+  }
+  const int tile = pyz_xcd_remap(blockIdx.x, g.tiles);
   int li = 0;
   while (li + 1 < g.L && tile >= g.lay[li + 1].tile0) ++li;
   const WgradLayer &ly = g.lay[li];
@@ -420,9 +547,6 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int mode = g.mode;
   const long long nstep = g.ctl->n;
   const float lr = g.ctl->lr;
-
-  // -- duties of the step that do not depend on this kernel's work; one spare wave, at the start
-  if (blockIdx.x == 0 && blockIdx.y == 0 && w == S - 1) pyz_step_duties(g, l);
 
   // -- epilogue operands of this thread's elements, fetched before the reduction so that
   //    their latency (and the Philox arithmetic) hides behind the operand loads / MFMAs

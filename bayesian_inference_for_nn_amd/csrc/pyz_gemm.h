@@ -248,7 +248,15 @@ __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap,
       },
       [&](int u, const float4 &a4) {
         const int c = w + S * u;
-        if (gp && c % copy_mod == copy_rem) *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
+        if (gp && c % copy_mod == copy_rem) {
+#ifdef PYZ_COPY_NT   // diagnostic: streaming stores for the batch copy
+          typedef float pyz_f4 __attribute__((ext_vector_type(4)));
+          pyz_f4 v = {a4.x, a4.y, a4.z, a4.w};
+          __builtin_nontemporal_store(v, reinterpret_cast<pyz_f4 *>(gp + 8 * c + 4 * h));
+#else
+          *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
+#endif
+        }
       });
   const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
   const unsigned vt = (unsigned)h * N4 + n4;

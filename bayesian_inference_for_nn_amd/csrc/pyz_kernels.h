@@ -31,9 +31,21 @@ __device__ __forceinline__ double pyz_block_sum(double v, double *sm) {
 // sum `n` partials in a fixed order -- called by ALL 64 lanes of one wave (lane l takes
 // part[l], part[l + 64], ...; then a shuffle tree); the total is valid in lane 0.
 // (A single thread walking the partials serialises n dependent memory round trips.)
+// The loads go out eight at a time: a lane's walk is a chain of dependent adds, and one load per
+// round trip would make 1024 partials (one per batch row, k_head_rows) cost 16 round trips.
 __device__ __forceinline__ double pyz_sum_partials(const double *part, int n) {
   double s = 0.0;
-  for (int i = threadIdx.x & 63; i < n; i += 64) s += part[i];
+  const int l = threadIdx.x & 63;
+  for (int i0 = 0; i0 < n; i0 += 512) {
+    double t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + 64 * j + l;
+      t[j] = i < n ? part[i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += t[j];
+  }
   return pyz_wave_sum(s);
 }
 

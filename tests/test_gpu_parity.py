@@ -53,6 +53,11 @@ SPECS = {
     "single_row": (o_mlp.MLPSpec((8, 8, 3), ("sigmoid", "softmax"), "scce"), 1),
     "small_reg2": (o_mlp.MLPSpec((3, 5, 2), ("tanh", "linear"), "mse"), 45),      # 2 layers + MSE: fused HMC kernel
     "hmc_regression": (o_mlp.MLPSpec((1, 1, 1), ("linear", "linear"), "mse"), 60),  # HMC_regression.py:36-39
+    # head kernels: one wave per row (k_head_rows) with MSE / several units per lane, and the MFMA head
+    # (k_head) that serves last layers too large for lane-resident operands
+    "reg_rows": (o_mlp.MLPSpec((6, 8, 2), ("tanh", "linear"), "mse"), 29),
+    "rows_ut4": (o_mlp.MLPSpec((10, 100, 5), ("sigmoid", "softmax"), "scce"), 41),
+    "mfma_head": (o_mlp.MLPSpec((8, 300, 32), ("relu", "softmax"), "scce"), 50),
 }
 
 

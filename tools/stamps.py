@@ -39,7 +39,7 @@ buf = (C.c_uint64 * (K * B * W * S * 2))()
 _lib.check(_lib.load().pyz_debug_stamps(buf, K * B * W * S * 2))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)
 names = {0: ("k_dense_fwd", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "end")], 224, 16),
-         1: ("k_head", [(0, "start"), (1, "addr ready"), (2, "accumulate done"), (3, "lds combined"), (4, "loss rows done"), (6, "delta_prev mfma issued"), (5, "end")], 32, 8),
+         1: ("k_head_rows", [(0, "start"), (1, "loads issued"), (2, "z reduced"), (3, "loss row done"), (4, "row stored"), (5, "end")], 256, 4),
          2: ("k_wgrad_all", [(0, "start"), (1, "addr+prefetch issued"), (2, "accumulate done"), (4, "tile reduced"), (3, "end")], 182, 16)}
 # global timeline of the last recorded step (s_memrealtime is one 100 MHz counter for the chip)
 g0 = None
@@ -50,6 +50,8 @@ for k, (nm, slots, nb, nw) in names.items():
     en = np.where(used, tt[:, :, slots[-1][0]], 0).max(axis=1)
     if g0 is None:
         g0 = st.min()
+    order = np.argsort(-en)[:6]
+    print(f"## {nm}: slowest workgroups (id: start..end): " + "  ".join(f"{int(b)}: {st[b] - g0:.0f}..{en[b] - g0:.0f}" for b in order))
     print(f"## {nm}: first wg start {st.min() - g0:7.0f}  last wg start {st.max() - g0:7.0f}  first wg end {en.min() - g0:7.0f}  "
           f"last wg end {en.max() - g0:7.0f}  (ns since the first forward workgroup started; waves/wg {used.sum(axis=1).max()})")
 for k, (nm, slots, nb, nw) in names.items():
