@@ -239,6 +239,24 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
 //   loss row, delta_L           every lane redundantly (N <= 32 values),
 //   delta_{L-1}[u] = act'(h[u]) * sum_c delta_L[c] W[u][c]   for the lane's own units,
 // with no LDS, no barrier and coalesced row loads / stores.  NP = padded class count.
+// value of lane `lane` (compile-time or wave-uniform) as a scalar
+__device__ __forceinline__ float pyz_readlane(const float v, const int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// every lane of a 16-lane row gets the row's sum: lane ^ 1, lane ^ 2 (quad permutes), then the
+// mirror inside each half row and the mirror of the row (data-parallel primitives: VALU speed)
+template <int CTRL>
+__device__ __forceinline__ float pyz_dpp(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pyz_row16_allsum(float v) {
+  v += pyz_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += pyz_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += pyz_dpp<0x141>(v);  // row_half_mirror
+  v += pyz_dpp<0x140>(v);  // row_mirror
+  return v;
+}
+
 template <int UT, int NP>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
@@ -282,13 +300,13 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
     for (int t = 0; t < UT; ++t) a = fmaf(hv[t], wv[t][c], a);
     z[c] = a;
   }
+  // sum over the 64 lanes without LDS traffic: four DPP steps leave each 16-lane row's sum in all its
+  // lanes, the four row sums are read as scalars and added in a fixed order (bitwise reproducible)
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-#pragma unroll
-    for (int c = 0; c < NP; ++c) z[c] += __shfl_xor(z[c], o, 64);
+  for (int c = 0; c < NP; ++c) {
+    const float v = pyz_row16_allsum(z[c]);
+    z[c] = ((pyz_readlane(v, 0) + pyz_readlane(v, 16)) + (pyz_readlane(v, 32) + pyz_readlane(v, 48))) + pyz_readlane(bias_mine, c);
   }
-#pragma unroll
-  for (int c = 0; c < NP; ++c) z[c] += __shfl(bias_mine, c, 64);
   PYZ_STAMP(1, 2);
   // ---- loss row and delta_L (every lane holds all N values; padded classes carry zeros)
   float d2[NP], outv[NP], lm;

@@ -116,7 +116,7 @@ __device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *
                                   const float *xs, float *d2, const float *yf, double *sm) {
   constexpr int SJ = MI + MC + 2;
   const int N = a.N, I = a.I, H = a.H, C = a.C;
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;  // w scalar: phase B's row slice lives in SGPRs
   const float *W1 = q, *b1 = q + I * H, *W2 = b1 + H, *b2 = W2 + H * C;
   for (int e = t; e < H * SJ; e += PYZ_HF_THREADS) {
     const int j = e / SJ, k = e - j * SJ;
