@@ -517,9 +517,10 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
 // the descriptor's byte count makes the row past an odd batch read as zero (no per-step row masks).
 // Requires batch * row bytes < 2^31 (checked when the plan is created).
 
+template <class H>
 __device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *abase, const int ic, const float *dbase,
                                                      const int n, const int lda, const int N, const int batch, int s,
-                                                     const int se, const int h, const bool is_w, const bool is_b) {
+                                                     const int se, const int h, const bool is_w, const bool is_b, H hook) {
   const float bconst = is_b ? 1.0f : 0.0f;
   const unsigned a_lane = ((unsigned)h * (unsigned)lda + (unsigned)ic) * 4u;
   const unsigned d_lane = ((unsigned)h * (unsigned)N + (unsigned)n) * 4u;
@@ -534,7 +535,7 @@ __device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *a
         a = pyz_buf_load(ra, a_lane, (unsigned)PYZ_HOT(st, batch) * a_row2);
         d = pyz_buf_load(rd, d_lane, (unsigned)PYZ_HOT(st, batch) * d_row2);
       },
-      [&](int, float &a, float &) { a = is_w ? a : bconst; });
+      [&](int, float &a, float &) { a = is_w ? a : bconst; }, hook);
 }
 
 // S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread)
@@ -566,33 +567,46 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const long long nstep = g.ctl->n;
   const float lr = g.ctl->lr;
 
-  // -- epilogue operands of this thread's elements, fetched before the reduction so that
-  //    their latency (and the Philox arithmetic) hides behind the operand loads / MFMAs
+  // -- epilogue operands of this thread's elements and the Philox noise: needed only after the
+  //    reduction, so they are fetched / generated right behind the first group of operand loads
+  //    (the hook of the pipelined loop) and their latency hides behind the loads and MFMAs
   long long ee[EPT];
   bool ev[EPT];
   float th0[EPT], mu0[EPT], sq0[EPT], zz[EPT];
+  auto prefetch = [&]() {
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) {
-    int ro, co;
-    if (S == 1) {
-      ro = (q & 3) + 8 * (q >> 2) + 4 * h;
-      co = r;
-    } else {
-      const int e = threadIdx.x + q * 64 * S;
-      ro = e >> 5;
-      co = e & 31;
+    for (int q = 0; q < EPT; ++q) {
+      int ro, co;
+      if (S == 1) {
+        ro = (q & 3) + 8 * (q >> 2) + 4 * h;
+        co = r;
+      } else {
+        const int e = threadIdx.x + q * 64 * S;
+        ro = e >> 5;
+        co = e & 31;
+      }
+      const int ii = i0 + ro, nn = n0 + co;
+      ev[q] = ii <= K && nn < N;
+      ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
+      th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
+      if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
+      if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB || mode == PYZ_UPD_SWAG) {
+        mu0[q] = g.mean[ee[q]];
+        sq0[q] = g.sq_mean[ee[q]];
+        if (g.unit_noise && mode != PYZ_UPD_SWAG) zz[q] = g.unit_noise[ee[q]];
+      }
     }
-    const int ii = i0 + ro, nn = n0 + co;
-    ev[q] = ii <= K && nn < N;
-    ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
-    th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
-    if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
-    if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB || mode == PYZ_UPD_SWAG) {
-      mu0[q] = g.mean[ee[q]];
-      sq0[q] = g.sq_mean[ee[q]];
-      if (g.unit_noise && mode != PYZ_UPD_SWAG) zz[q] = g.unit_noise[ee[q]];
+    if ((mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) {
+        const float4 nq = mode == PYZ_UPD_SGLD
+                              ? pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2))
+                              : pyz_normal4(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)(ee[q] >> 2));
+        const int k = (int)(ee[q] & 3);
+        zz[q] = k == 0 ? nq.x : (k == 1 ? nq.y : (k == 2 ? nq.z : nq.w));
+      }
     }
-  }
+  };
 
   const int i = i0 + r, n = min(n0 + r, N - 1);
   const int ic = min(i, K - 1);
@@ -606,6 +620,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int se = (steps * (w + 1)) / S;
   PYZ_STAMP(2, 1);
   if (idx) {
+    prefetch();
     // gathered rows: the 64 row indices of a 32-step chunk come from ONE coalesced load (lane j
     // holds the index of batch row 2*s0 + j) and reach the step that needs them by a lane
     // permute, so the pipelined operand loads never wait on an index load
@@ -628,17 +643,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
     }
   } else {
     pyz_wgrad_accumulate(acc, ly.in + p * ly.in_pstride, ic, ly.delta + p * ly.delta_pstride, n, ly.lda, N, batch, s, se, h,
-                         is_w, is_b);
-  }
-  if ((mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const float4 nq = mode == PYZ_UPD_SGLD
-                            ? pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2))
-                            : pyz_normal4(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)(ee[q] >> 2));
-      const int k = (int)(ee[q] & 3);
-      zz[q] = k == 0 ? nq.x : (k == 1 ? nq.y : (k == 2 ? nq.z : nq.w));
-    }
+                         is_w, is_b, prefetch);
   }
   PYZ_STAMP(2, 2);
   float gv[EPT];

@@ -129,13 +129,25 @@ struct PyzNoFix {
   __device__ __forceinline__ void operator()(int, float &, float &) const {}
 };
 
-template <int G, class L, class F>
-__device__ __forceinline__ void pyz_pipe1(int s, const int se, f32x16 &acc, L load, F fix) {
-  if (s >= se) return;
+struct PyzNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `hook` runs once, right after the first group's loads have been issued: work that needs no operand
+// (prefetches for the epilogue, noise generation) then sits in the shadow of that first round trip
+template <int G, class L, class F, class H = PyzNoHook>
+__device__ __forceinline__ void pyz_pipe1(int s, const int se, f32x16 &acc, L load, F fix, H hook = H()) {
+  if (s >= se) {
+    hook();
+    return;
+  }
   float an[G], bn[G], a[G], b[G];
   const int last = se - 1;
 #pragma unroll
   for (int u = 0; u < G; ++u) load(min(s + u, last), an[u], bn[u]);
+  __builtin_amdgcn_sched_barrier(0);
+  hook();
+  __builtin_amdgcn_sched_barrier(0);
   for (;;) {
     // the copy is the wait for the loads issued one group ago; a single-phase loop keeps
     // the compiler's vmcnt bookkeeping exact (a ping-pong body drains at the back edge)
@@ -208,9 +220,9 @@ template <class L, class U>
 __device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load, U use) {
   pyz_pipe4<2>(c, ce, acc, load, use);
 }
-template <class L, class F>
-__device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load, F fix) {
-  pyz_pipe1<8>(s, se, acc, load, fix);
+template <class L, class F, class H = PyzNoHook>
+__device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load, F fix, H hook = H()) {
+  pyz_pipe1<8>(s, se, acc, load, fix, hook);
 }
 
 // ---------------------------------------------------------------- forward
