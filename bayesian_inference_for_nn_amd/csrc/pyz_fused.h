@@ -272,10 +272,10 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   if (g.row_idx) yrow = g.row_idx[g.ctl->row_off + m];
   const float *hp = g.hin + p * g.hin_pstride + (g.gather_hin ? yrow : (long long)m) * g.lda;
   const float *wl = g.theta + p * g.theta_pstride + g.w_off;
-  // Operands through buffer descriptors: per-lane unit offset (voffset) + scalar class offset.  Units
-  // past K and classes past N read as zero (offsets beyond the descriptors' byte counts), so the
-  // class loops below are straight-line code over the NP padded classes: no per-class branches
-  // (conditional writes into the register arrays would turn them into whole-vector copies).
+  // Operands through buffer descriptors (per-lane byte offsets, range checked against the byte count):
+  // units past K read as zero.  The class loops below are straight-line code over the NP padded
+  // classes: no per-class branches (conditional writes into the register arrays would turn them
+  // into whole-vector copies).
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (K + 1) * N * 4, 0x00020000);
   constexpr unsigned OOB = 0x7FFFFF00u;
@@ -284,11 +284,14 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   for (int t = 0; t < UT; ++t) {
     const int u = l + 64 * t;
     hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
+    // only the per-lane offset is range checked by the hardware (not the scalar one): units past K get an
+    // out-of-range voffset; a padded class c >= N reads a neighbouring in-range element (or 0 past the
+    // end), which is harmless: z[c] is never used and delta_L[c] = 0 multiplies it below
     const unsigned wo = u < K ? 4u * (unsigned)u * (unsigned)N : OOB;
 #pragma unroll
-    for (int c = 0; c < NP; ++c) wv[t][c] = pyz_buf_load(rw, wo, c < N ? 4u * (unsigned)c : OOB);
+    for (int c = 0; c < NP; ++c) wv[t][c] = pyz_buf_load(rw, wo + 4u * (unsigned)c, 0u);
   }
-  const float bias_mine = pyz_buf_load(rw, l < N ? 4u * (unsigned)l : OOB, 4u * (unsigned)K * (unsigned)N);  // lane c: b[c]
+  const float bias_mine = pyz_buf_load(rw, l < N ? 4u * ((unsigned)K * (unsigned)N + (unsigned)l) : OOB, 0u);  // lane c: b[c]
   int ylab = 0;
   if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
   PYZ_STAMP(1, 1);
@@ -513,8 +516,7 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
 
 // contiguous (no gather) reduction over the batch rows, software pipelined.  Operands come through
 // buffer descriptors built from wave-uniform bases: a step's address is a scalar row offset
-// (soffset) plus a per-lane constant (voffset), so the loop spends no vector ALU on addressing, and
-// the descriptor's byte count makes the row past an odd batch read as zero (no per-step row masks).
+// (soffset) plus a per-lane constant (voffset), so the loop spends no vector ALU on addressing.
 // Requires batch * row bytes < 2^31 (checked when the plan is created).
 
 template <class H>
@@ -529,13 +531,22 @@ __device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *a
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(abase), 0, (int)((unsigned)batch * (unsigned)lda * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dbase), 0, (int)((unsigned)batch * (unsigned)N * 4u), 0x00020000);
+  // only whole steps here: the scalar offset is not range checked, so the odd last row is peeled
+  const int full = batch >> 1;
   pyz_steps1_all(
-      s, se, acc,
+      s, min(se, full), acc,
       [&](int st, float &a, float &d) {
         a = pyz_buf_load(ra, a_lane, (unsigned)PYZ_HOT(st, batch) * a_row2);
         d = pyz_buf_load(rd, d_lane, (unsigned)PYZ_HOT(st, batch) * d_row2);
       },
       [&](int, float &a, float &) { a = is_w ? a : bconst; }, hook);
+  if (se > full) {  // this wave owns the odd last row: the second reduction slot of its MFMA stays empty
+    const int b = batch - 1;
+    float a = abase[(size_t)b * lda + ic], d = dbase[(size_t)b * N + n];
+    a = h == 0 ? (is_w ? a : bconst) : 0.0f;
+    d = h == 0 ? d : 0.0f;
+    acc = pyz_mfma(a, d, acc);
+  }
 }
 
 // S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread)

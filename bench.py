@@ -177,7 +177,7 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        # The step is three kernels (k_dense_fwd, k_head, k_wgrad_all).  Their in-pipeline durations are
+        # The step is three kernels (k_dense_fwd, k_head_rows, k_wgrad_all).  Their in-pipeline durations are
         # measured live with HIP events recorded on the bench stream around every kernel of 256 further
         # steps of the same chain (eager launches: an event cannot sit inside a graph node sequence).
         n_prof = 256
@@ -188,7 +188,7 @@ def main():
         with torch.cuda.stream(stream):
             plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes[:16], plr[:16], total, SEED + rank, plosses)   # warm
             us = plan.sgld_profile(theta, mean, sq_mean, x, y, pidx, psizes, plr, total + 16, SEED + rank, plosses)
-        names = ["k_dense_fwd", "k_head", "k_wgrad_all"]
+        names = ["k_dense_fwd", "k_head_rows", "k_wgrad_all"]
         us = list(us)
         # An event record between two kernels costs queue time of its own (the instrumented step is
         # slower than the timed region's).  The kernels tile the step, so the per-record overhead is

@@ -4,7 +4,7 @@ profiles/r01_pmc_traffic.json: HBM bytes per launch of each kernel of the SGLD s
 Units and corrections per MI355X_MICROARCH.md (section HBM): both counters are in KB; on gfx950
 FETCH_SIZE reports half the bytes of a WIDE (16 B/lane) coalesced stream and is uncalibrated for
 other widths, so it is calibrated here on a known byte count in our own access pattern:
-k_wgrad_all reads X (3.21 MB) + delta_1 (0.82) + H (0.82) + delta_2 (0.04) + theta, mean, sq_mean
+k_wgrad_all reads the batch copy of X (3.21 MB) + delta_1 (0.82) + H (0.82) + delta_2 (0.04) + theta, mean, sq_mean
 (1.91) = 6.80 MB by construction and the raw counter says 6.95 MB (ratio 1.02; WRITE_SIZE 1.86 MB
 vs 1.91 MB written).  The dword / fragment operand loads of these kernels are therefore counted
 at face value; the x2 figure is kept as an upper bound."""
@@ -31,19 +31,22 @@ def agg(pattern, counter):
 def main():
     fdir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_fetch")
     wdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "pmc_write")
-    f = agg(os.path.join(fdir, "*", "*counter_collection.csv"), "FETCH_SIZE")
-    w = agg(os.path.join(wdir, "*", "*counter_collection.csv"), "WRITE_SIZE")
+    # a directory of rocprofv3 output (<dir>/<host>/<pid>_counter_collection.csv) or one csv file
+    fpat = fdir if fdir.endswith(".csv") else os.path.join(fdir, "*", "*counter_collection.csv")
+    wpat = wdir if wdir.endswith(".csv") else os.path.join(wdir, "*", "*counter_collection.csv")
+    f = agg(fpat, "FETCH_SIZE")
+    w = agg(wpat, "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-roofline",
            "units": "counters in KB; hbm_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) * 1024, calibrated on the known byte count of k_wgrad_all (see tools/pmc_traffic.py); hbm_bytes_upper_bound applies the x2 FETCH_SIZE correction of 16-B/lane streams",
            "kernels": {}}
-    for k in ("k_dense_fwd", "k_head", "k_wgrad_all"):
+    for k in ("k_dense_fwd", "k_head_rows", "k_head", "k_wgrad_all"):
         if k in f:
             fk = sum(f[k]) / len(f[k])
             wk = sum(w[k]) / len(w[k]) if k in w else 0.0
             out["kernels"][k] = {"launches": len(f[k]), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
                                  "hbm_bytes_per_launch": int((fk + wk) * 1024),
                                  "hbm_bytes_upper_bound": int((2 * fk + wk) * 1024)}
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
