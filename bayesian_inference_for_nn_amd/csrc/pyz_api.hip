@@ -9,6 +9,7 @@
 #include "pyz_fused.h"
 #include "pyz_gemm.h"
 #include "pyz_hmc_fused.h"
+#include "pyz_hmc_multi.h"
 #include "pyz_kernels.h"
 #include "pyz_rng.h"
 
@@ -30,6 +31,11 @@ int ensure_bytes(void **ptr, size_t *cap, size_t need, pyz_mlp *m) {
 
 struct Extra {  // lazily sized buffers kept beside the plan
   size_t grad_cap = 0, grad2_cap = 0, qsave_cap = 0, part_cap = 0, part2_cap = 0, scal_cap = 0;
+  void *hm_buf = nullptr;  // k_hmc_multi: state / slab ping-pong buffers
+  size_t hm_cap = 0;
+  hipGraph_t hm_graph = nullptr;  // the launch sequence of one sliced HMC proposal
+  hipGraphExec_t hm_exec = nullptr;
+  unsigned long long hm_key = 0;
   double *part2 = nullptr;
   size_t tab_cap_bytes = 0;
   void *tab_host = nullptr;  // pinned
@@ -440,11 +446,13 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
   pyz_mlp_full *m = full(mm);
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->x.hm_exec) (void)hipGraphExecDestroy(m->x.hm_exec);
+  if (m->x.hm_graph) (void)hipGraphDestroy(m->x.hm_graph);
   for (int l = 0; l < PYZ_MAX_LAYERS; ++l) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr, m->xb};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr, m->xb, m->x.hm_buf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) (void)hipHostFree(m->x.tab_host);
@@ -833,16 +841,29 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   pyz_mlp_full *f = full(m);
   float *loss = m->scal;               // [P]
   float *energies = m->scal + m->max_p;  // [P*8]
-  float *unif = m->scal + 9 * m->max_p;  // [P]
-  PYZ_HIP(hipMemcpyAsync(unif, h_uniform, sizeof(float) * P, hipMemcpyHostToDevice, st));
+  float *unif = m->scal + 9 * m->max_p;  // [max_p] uniforms, then one HmcCall
+  HmcCall *call_dev = reinterpret_cast<HmcCall *>(m->scal + 10 * m->max_p);  // float index 10 max_p is even
+  {
+    std::vector<unsigned char> up(sizeof(float) * (size_t)m->max_p + sizeof(HmcCall));
+    memcpy(up.data(), h_uniform, sizeof(float) * P);
+    HmcCall hc{seed, (uint32_t)step, burning ? 1 : 0};
+    memcpy(up.data() + sizeof(float) * (size_t)m->max_p, &hc, sizeof hc);
+    PYZ_HIP(hipMemcpyAsync(unif, up.data(), up.size(), hipMemcpyHostToDevice, st));
+  }
   {
     // small 2-layer models: the whole proposal in one workgroup per chain (pyz_hmc_fused.h)
     const int allow_fused = pyz_env_int("PYZ_HMC_FUSED", 1);  // read per call: tests flip it
     const int I = m->dims[0], H = m->dims[1], C = m->L == 2 ? m->dims[2] : 0;
     const int MIC = (I <= 2 && C <= 2) ? 2 : ((I <= 4 && C <= 4) ? 4 : 8);
     const size_t lds = m->L == 2 ? pyz_hmc_fused_lds_bytes(n_rows, MIC, MIC, C, (int)m->D, m->loss) : 0;
-    if (allow_fused && !d_prior_mean_vec && !d_prior_sigma_vec && m->L == 2 && I <= PYZ_HF_MAXI && C <= PYZ_HF_MAXC && H + C <= 64 && lds <= 150 * 1024 &&
-        m->acts[0] != PYZ_ACT_SOFTMAX) {
+    // (the one-workgroup form needs the whole data set in LDS; the sliced form only its slice)
+    const int allow_multi = pyz_env_int("PYZ_HMC_MULTI", 1);  // read per call: tests flip it
+    const int rows_per_wg = std::max(16, pyz_env_int("PYZ_HMC_ROWS_PER_WG", 96));
+    const int NW = std::min(PYZ_HM_MAXW, n_rows / rows_per_wg);
+    const size_t mlds = m->L == 2 ? pyz_hmc_multi_lds_bytes(cdiv(n_rows, std::max(NW, 1)) + 1, MIC, MIC, C, (int)m->D, m->loss) : 0;
+    const bool multi_ok = allow_multi && NW >= 2 && P <= pyz_env_int("PYZ_HMC_MULTI_MAX_CHAINS", 16) && mlds <= 150 * 1024;
+    if (allow_fused && !d_prior_mean_vec && !d_prior_sigma_vec && m->L == 2 && I <= PYZ_HF_MAXI && C <= PYZ_HF_MAXC && H + C <= 64 &&
+        (lds <= 150 * 1024 || multi_ok) && m->acts[0] != PYZ_ACT_SOFTMAX) {
       HmcFusedArgs f{};
       f.q = d_q;
       f.x = d_x;
@@ -877,6 +898,73 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
         default: PYZ_HF_PICK(PYZ_ACT_LINEAR); break;
       }
 #undef PYZ_HF_PICK
+      // few chains: spread each one over NW workgroups, one launch per gradient evaluation (pyz_hmc_multi.h);
+      // many chains: one workgroup per chain, the whole proposal in one launch
+      if (multi_ok) {
+        HmcMultiArgs mm{};
+        mm.f = f;
+        mm.NW = NW;
+        mm.max_rows = cdiv(n_rows, NW) + 1;
+        const size_t D = (size_t)m->D;
+        const size_t n_state = 2 * (size_t)P * D, n_slab = 2 * (size_t)P * NW * D;
+        const size_t bytes = sizeof(float) * (2 * n_state + n_slab + 4 * (size_t)P) + sizeof(double) * 2 * (size_t)P * NW + 64;
+        pyz_mlp_full *fm = full(m);
+        if ((rc = ensure_bytes(&fm->x.hm_buf, &fm->x.hm_cap, bytes, m))) return rc;
+        mm.lpart = reinterpret_cast<double *>(fm->x.hm_buf);  // doubles first: 8-byte aligned
+        mm.qw = reinterpret_cast<float *>(mm.lpart + 2 * (size_t)P * NW);
+        mm.pw = mm.qw + n_state;
+        mm.slab = mm.pw + n_state;
+        mm.scal = mm.slab + n_slab;
+        void (*kmulti)(HmcMultiArgs) = nullptr;
+#define PYZ_HM_PICK(ACT)                                                                         \
+  kmulti = bucket == 0 ? k_hmc_multi<2, 2, ACT> : (bucket == 1 ? k_hmc_multi<4, 4, ACT> : k_hmc_multi<8, 8, ACT>)
+        switch (m->acts[0]) {
+          case PYZ_ACT_RELU: PYZ_HM_PICK(PYZ_ACT_RELU); break;
+          case PYZ_ACT_TANH: PYZ_HM_PICK(PYZ_ACT_TANH); break;
+          case PYZ_ACT_SIGMOID: PYZ_HM_PICK(PYZ_ACT_SIGMOID); break;
+          default: PYZ_HM_PICK(PYZ_ACT_LINEAR); break;
+        }
+#undef PYZ_HM_PICK
+        if (mlds > 64 * 1024)
+          PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kmulti), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        mm.call = call_dev;
+        // one graph per (kernel, shapes, pointers, scalars): a proposal is L + 2 dependent launches
+        unsigned long long key = 1469598103934665603ull;
+        auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+        mix((unsigned long long)(uintptr_t)kmulti); mix((unsigned long long)L); mix((unsigned long long)P); mix((unsigned long long)NW);
+        mix((unsigned long long)n_rows); mix((unsigned long long)(uintptr_t)d_q); mix((unsigned long long)(uintptr_t)d_x);
+        mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_unit_p); mix((unsigned long long)(uintptr_t)d_stats);
+        mix((unsigned long long)(uintptr_t)fm->x.hm_buf); mix((unsigned long long)(uintptr_t)st);
+        unsigned fbits[4];
+        memcpy(&fbits[0], &epsilon, 4); memcpy(&fbits[1], &mass, 4); memcpy(&fbits[2], &prior_mean, 4); memcpy(&fbits[3], &prior_sigma, 4);
+        for (unsigned b : fbits) mix(b);
+        static const int use_graph = pyz_env_int("PYZ_HMC_GRAPH", 1);
+        auto launch_all = [&]() {
+          for (int t = 0; t <= L; ++t) {
+            mm.t = t;
+            hipLaunchKernelGGL(kmulti, dim3(NW, P), dim3(PYZ_HM_THREADS), mlds, st, mm);
+          }
+          hipLaunchKernelGGL(k_hmc_multi_final, dim3(P), dim3(PYZ_HM_THREADS), 0, st, mm);
+        };
+        if (!use_graph || st == nullptr) {  // the legacy default stream cannot be captured
+          launch_all();
+          PYZ_LAUNCH_CHECK();
+          return PYZ_OK;
+        }
+        if (!fm->x.hm_exec || fm->x.hm_key != key) {
+          if (fm->x.hm_exec) { (void)hipGraphExecDestroy(fm->x.hm_exec); fm->x.hm_exec = nullptr; }
+          if (fm->x.hm_graph) { (void)hipGraphDestroy(fm->x.hm_graph); fm->x.hm_graph = nullptr; }
+          PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+          launch_all();
+          hipGraph_t gr = nullptr;
+          PYZ_HIP(hipStreamEndCapture(st, &gr));
+          fm->x.hm_graph = gr;
+          PYZ_HIP(hipGraphInstantiate(&fm->x.hm_exec, fm->x.hm_graph, nullptr, nullptr, 0));
+          fm->x.hm_key = key;
+        }
+        PYZ_HIP(hipGraphLaunch(fm->x.hm_exec, st));
+        return PYZ_OK;
+      }
       if (lds > 64 * 1024)
         PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, dim3(P), dim3(PYZ_HF_THREADS), lds, st, f);

@@ -55,6 +55,7 @@ static inline size_t pyz_hmc_fused_lds_bytes(int N, int MI, int MC, int C, int D
   return ((pyz_hmc_fused_floats(N, MI, MC, C, D, loss) * 4 + 15) / 16) * 16 + 64 * sizeof(double);
 }
 
+template <int WAVES = PYZ_HF_WAVES>
 __device__ __forceinline__ double pyz_hf_block_sum(double v, double *sm) {
   v = pyz_wave_sum(v);
   __syncthreads();
@@ -62,7 +63,7 @@ __device__ __forceinline__ double pyz_hf_block_sum(double v, double *sm) {
   __syncthreads();
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < PYZ_HF_WAVES; ++i) s += sm[i];
+  for (int i = 0; i < WAVES; ++i) s += sm[i];
   return s;  // every thread gets the same total
 }
 
@@ -107,18 +108,21 @@ __device__ __forceinline__ double pyz_hf_row_tail(const HmcFusedArgs &a, const f
   return (double)(acc / (float)C);
 }
 
-// mean loss and its gradient (into g[]) at the weights q[] (both LDS); returns the mean loss.
+// sum of the row losses over the nloc rows staged in xs / yf, and the gradient of (that sum / N) into
+// g[] at the weights q[] (both LDS).  WAVES = waves of the workgroup (16: the whole data set in one
+// workgroup, k_hmc_fused; 4: a row slice, k_hmc_multi).
 // MI / MC = compile-time widths the rows are padded to; ACT = the hidden activation, a template
 // parameter so that the inner loops carry exactly one activation's code.
 // wj[j] = { W1[0..MI)[j], W2[j][0..MC), b1[j], 0 } is rebuilt from q at every call.
-template <int MI, int MC, int ACT>
-__device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *g, float *part, float *wj,
-                                  const float *xs, float *d2, const float *yf, double *sm) {
+template <int MI, int MC, int ACT, int WAVES = PYZ_HF_WAVES>
+__device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *g, float *part, float *wj,
+                                   const float *xs, float *d2, const float *yf, double *sm, const int nloc) {
   constexpr int SJ = MI + MC + 2;
-  const int N = a.N, I = a.I, H = a.H, C = a.C;
+  constexpr int THREADS = 64 * WAVES;
+  const int N = nloc, I = a.I, H = a.H, C = a.C;
   const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;  // w scalar: phase B's row slice lives in SGPRs
   const float *W1 = q, *b1 = q + I * H, *W2 = b1 + H, *b2 = W2 + H * C;
-  for (int e = t; e < H * SJ; e += PYZ_HF_THREADS) {
+  for (int e = t; e < H * SJ; e += THREADS) {
     const int j = e / SJ, k = e - j * SJ;
     float v = 0.0f;
     if (k < MI) v = k < I ? W1[k * H + j] : 0.0f;
@@ -129,8 +133,8 @@ __device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *
   __syncthreads();
   // ---------------- phase A: rows (two per pass: every weight record read feeds two rows)
   double lsum = 0.0;
-  for (int r0 = t; r0 < N; r0 += 2 * PYZ_HF_THREADS) {
-    const int r1 = r0 + PYZ_HF_THREADS;
+  for (int r0 = t; r0 < N; r0 += 2 * THREADS) {
+    const int r1 = r0 + THREADS;
     const bool has1 = r1 < N;
     const int r1c = has1 ? r1 : r0;
     float x0[MI], x1[MI], z0[MC], z1[MC];
@@ -161,7 +165,7 @@ __device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *
     lsum += pyz_hf_row_tail<MC>(a, z0, d2 + r0 * MC, yf, r0);
     if (has1) lsum += pyz_hf_row_tail<MC>(a, z1, d2 + r1 * MC, yf, r1);
   }
-  const float loss = (float)(pyz_hf_block_sum(lsum, sm) / (double)N);  // also orders d2[] before phase B
+  const double loss = pyz_hf_block_sum<WAVES>(lsum, sm);  // also orders d2[] before phase B
   PYZ_STAMP(3, 5);
   // ---------------- phase B: lane <-> hidden unit, wave <-> row slice
   {
@@ -184,7 +188,7 @@ __device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *
       gw2[c] = 0.0f;
     }
     const float bj = rec[MI + MC];
-    const int rb = (int)(((long long)N * w) / PYZ_HF_WAVES), re = (int)(((long long)N * (w + 1)) / PYZ_HF_WAVES);
+    const int rb = (int)(((long long)N * w) / WAVES), re = (int)(((long long)N * (w + 1)) / WAVES);
     // four rows per trip: their LDS reads are issued together and the four dependent
     // chains (pre -> h -> dh -> dpre) interleave instead of serialising on LDS latency
     for (int r = rb; r < re; r += 4) {
@@ -227,10 +231,10 @@ __device__ float pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *
   }
   PYZ_STAMP(3, 6);
   __syncthreads();
-  for (int e = t; e < a.D; e += PYZ_HF_THREADS) {
+  for (int e = t; e < a.D; e += THREADS) {
     float s = part[e];
 #pragma unroll
-    for (int ww = 1; ww < PYZ_HF_WAVES; ++ww) s += part[ww * a.D + e];
+    for (int ww = 1; ww < WAVES; ++ww) s += part[ww * a.D + e];
     g[e] = s;
   }
   __syncthreads();
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(PYZ_HF_THREADS) k_hmc_fused(HmcFusedArgs a) {
   const float isig2 = 1.0f / (a.prior_sigma * a.prior_sigma);
   PYZ_STAMP(3, 1);
   // ---- U0, K0 and the first gradient (HMC.py:79-82)
-  const float loss0 = pyz_hf_loss_grad<MI, MC, ACT>(a, q, g, part, wj, xs, d2, yf, sm);
+  const float loss0 = (float)(pyz_hf_loss_grad<MI, MC, ACT>(a, q, g, part, wj, xs, d2, yf, sm, N) / (double)N);
   PYZ_STAMP(3, 2);
   float U0 = 0.0f - slp_0;
   U0 = U0 + loss0 * n_train;
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(PYZ_HF_THREADS) k_hmc_fused(HmcFusedArgs a) {
   }
   __syncthreads();
   for (int it = 1; it <= a.L; ++it) {
-    loss1 = pyz_hf_loss_grad<MI, MC, ACT>(a, q, g, part, wj, xs, d2, yf, sm);
+    loss1 = (float)(pyz_hf_loss_grad<MI, MC, ACT>(a, q, g, part, wj, xs, d2, yf, sm, N) / (double)N);
     for (int e = t; e < D; e += PYZ_HF_THREADS) {
       const float dU = (q[e] - a.prior_mean) * isig2 + n_train * g[e];
       float pv = p[e] - eps * dU;

@@ -51,20 +51,27 @@ class HMC(Optimizer):
             self._pm_vec, self._ps_vec = torch.as_tensor(mu.copy()).cuda(), torch.as_tensor(sg.copy()).cuda()
         self._q = torch.as_tensor(np.repeat(mu[None, :], self._n_chains, axis=0).copy()).cuda()
         self._stats = torch.zeros((self._n_chains, 8), device="cuda")
+        # proposals run on a stream of their own: the library replays the launch sequence of a sliced
+        # proposal as a hipGraph, and the legacy default stream cannot be captured
+        self._stream = torch.cuda.Stream()
         self._step_count = 0
         self._chain_samples = [[] for _ in range(self._n_chains)]
         self._chain_freq = [[] for _ in range(self._n_chains)]
 
     def step(self, save_document_path=None, sampling=True, burning=False):
+        import torch
         if sampling:
             for c in range(self._n_chains):                    # HMC.py:75-77: records the starting q
                 if len(self._chain_freq[c]) == 0:
                     self._chain_freq[c].append(1)
                     self._chain_samples[c].append(self._q[c].clone())
         uniforms = [random.random() for _ in range(self._n_chains)]      # HMC.py:91 host Mersenne Twister
-        self._plan.hmc_step(self._q, self._x_dev, self._y_dev, int(self._L), self._epsilon, self._m, self._prior_mean,
-                            self._prior_sigma, uniforms, self._step_count, self._seed, self._stats, burning=burning,
-                            prior_mean_vec=self._pm_vec, prior_sigma_vec=self._ps_vec)
+        self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):
+            self._plan.hmc_step(self._q, self._x_dev, self._y_dev, int(self._L), self._epsilon, self._m, self._prior_mean,
+                                self._prior_sigma, uniforms, self._step_count, self._seed, self._stats, burning=burning,
+                                prior_mean_vec=self._pm_vec, prior_sigma_vec=self._ps_vec)
+        torch.cuda.current_stream().wait_stream(self._stream)
         self._step_count += 1
         stats = self._stats.cpu().numpy()
         self._total_runs += 1

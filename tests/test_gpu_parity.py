@@ -58,6 +58,9 @@ SPECS = {
     "reg_rows": (o_mlp.MLPSpec((6, 8, 2), ("tanh", "linear"), "mse"), 29),
     "rows_ut4": (o_mlp.MLPSpec((10, 100, 5), ("sigmoid", "softmax"), "scce"), 41),
     "mfma_head": (o_mlp.MLPSpec((8, 300, 32), ("relu", "softmax"), "scce"), 50),
+    # sliced HMC (k_hmc_multi): 7 and 3 row slices per chain
+    "moons_700": (o_mlp.MLPSpec((2, 50, 2), ("relu", "softmax"), "scce"), 700),
+    "hmc_multi_mse": (o_mlp.MLPSpec((3, 5, 2), ("tanh", "linear"), "mse"), 301),
 }
 
 
@@ -342,13 +345,16 @@ def test_list_valued_priors_bbb_and_hmc(eng, monkeypatch):
 
 
 # ------------------------------------------------------------------ HMC
-@pytest.mark.parametrize("name,L,fused", [("moons", 5, 1), ("moons", 5, 0), ("linreg", 3, 1), ("tiny_cls", 0, 1),
-                                          ("tiny_cls", 2, 0), ("reg3", 2, 1), ("small_reg2", 3, 1), ("small_reg2", 3, 0),
-                                          ("hmc_regression", 4, 1)])
-def test_hmc_step_matches_oracle(eng, name, L, fused, monkeypatch):
-    """fused = 1: small 2-layer models run the single-workgroup kernel (pyz_hmc_fused.h);
-    fused = 0 forces the generic multi-launch path on the same inputs."""
+@pytest.mark.parametrize("name,L,fused,multi", [("moons", 5, 1, 1), ("moons", 5, 1, 0), ("moons", 5, 0, 0), ("moons_700", 4, 1, 1),
+                                                ("moons_700", 0, 1, 1), ("moons_700", 1, 1, 1), ("hmc_multi_mse", 3, 1, 1),
+                                                ("linreg", 3, 1, 1), ("tiny_cls", 0, 1, 1), ("tiny_cls", 2, 0, 0), ("reg3", 2, 1, 1),
+                                                ("small_reg2", 3, 1, 1), ("small_reg2", 3, 0, 0), ("hmc_regression", 4, 1, 1)])
+def test_hmc_step_matches_oracle(eng, name, L, fused, multi, monkeypatch):
+    """fused = 1: small 2-layer models run inside workgroups that keep the chain state in LDS -- one per
+    chain (pyz_hmc_fused.h), or, with multi = 1 and at least 192 rows, NW row slices per chain and one
+    launch per gradient evaluation (pyz_hmc_multi.h); fused = 0 forces the generic multi-launch path."""
     monkeypatch.setenv("PYZ_HMC_FUSED", str(fused))
+    monkeypatch.setenv("PYZ_HMC_MULTI", str(multi))
     spec, n = SPECS[name]
     x, y, q0 = make(spec, n, seed=41, scale=0.2)
     D = spec.n_params
@@ -369,6 +375,16 @@ def test_hmc_step_matches_oracle(eng, name, L, fused, monkeypatch):
     stats = torch.zeros((P, 8), device="cuda")
     plan.hmc_step(q, dev(x), ydev(spec, y), L, eps_, m, 0.0, 1.0, us, 0, 1, stats, unit_p=dev(zs))
     s = stats.cpu().numpy()
+    if multi:   # on a side stream the sliced path replays a captured graph: same bits, twice
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            qg, sg = dev(qs), torch.zeros((P, 8), device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                plan.hmc_step(qg, dev(x), ydev(spec, y), L, eps_, m, 0.0, 1.0, us, 0, 1, sg, unit_p=dev(zs))
+            side.synchronize()
+            assert torch.equal(qg, q) and torch.equal(sg, stats)
     for c, r in enumerate(refs):
         assert bool(s[c, 0]) == r["accepted"], (c, s[c], r["log_ratio"])
         close(q[c], r["q"], what=f"q[{c}]")
