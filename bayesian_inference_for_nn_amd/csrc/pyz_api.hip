@@ -1085,7 +1085,31 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
   a.nblk = nblk;
   const size_t lds = sizeof(double) * (size_t)(5 * n_total);
   const int jgroups = cdiv(n_total, 8);
-  if (sweep == PYZ_SWEEP_JACOBI) {
+  static const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);
+  if (sweep == PYZ_SWEEP_JACOBI && tiles_on && n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles) {
+    // every row from the same snapshot: the particle matrix is read once per pass (k_svgd_*_tile)
+    SvgdTileArgs ta{};
+    ta.particles = d_particles;
+    ta.all = d_all;
+    ta.adam_m = d_adam_m;
+    ta.adam_v = d_adam_v;
+    ta.grad = m->grad;
+    ta.D = m->D;
+    ta.M = n_total;
+    ta.n_local = n_local;
+    ta.row0 = row0;
+    ta.lr_t = a.lr_t;
+    ta.gamma = gamma;
+    ta.nblk = cdiv(m->D, PYZ_SV_R);
+    const size_t n_part = (size_t)n_local * ta.nblk * 64, n_k = (size_t)n_local * 64;
+    if ((rc = need_part2(m, n_part + n_k + n_local + 8))) return rc;
+    ta.part = full(m)->x.part2;
+    ta.kmat = ta.part + n_part;
+    ta.ksum = reinterpret_cast<float *>(ta.kmat + n_k);
+    hipLaunchKernelGGL(k_svgd_dist_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+    hipLaunchKernelGGL(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta);
+    hipLaunchKernelGGL(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), sizeof(double) * n_k + sizeof(float) * n_local, st, ta);
+  } else if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
     hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);

@@ -619,6 +619,187 @@ __global__ void __launch_bounds__(256) k_svgd_update(SvgdArgs g) {
   if (g.all_rw && g.all_rw != g.particles) g.all_rw[(long long)i * g.D + d] = xn;
 }
 
+// ---------------------------------------------------------------- Jacobi sweep, all rows at once
+// The per-row kernels above read the (M, D) particle matrix once per ROW: a Jacobi sweep of M = 64
+// rows moves 64 x 40.7 MB twice (distances, update).  With every row updated from the same snapshot
+// the matrix needs to be read once per pass:
+//   k_svgd_dist_tile   a workgroup owns PYZ_SV_R consecutive elements of D, stages 128-element slabs
+//                      of ALL particles in LDS ([element][particle]) and accumulates the float64
+//                      squared-distance partials of its 4 x 4 pair blocks (thread (ti, tj): local rows
+//                      4 ti .. + 3 against particles 4 tj .. + 3), the reference's arithmetic
+//                      (SVGD.py:198-201: differences and squares in float64);
+//   k_svgd_kmat        sums the partials of a row in block order, K_ij = exp(-gamma d_ij), sum_j K_ij;
+//   k_svgd_update_tile a thread owns ONE element d: it keeps x_j[d] of all particles in registers and
+//                      produces phi_i[d] + the Adam step for every local row i (the formulas and the
+//                      summation order over j of k_svgd_update).
+// Needs M <= 64 and local rows in multiples of 4 starting at a multiple of 4; else the per-row kernels run.
+#define PYZ_SV_R 512   // elements of D per workgroup of k_svgd_dist_tile
+#define PYZ_SV_E 128   // elements staged per pass
+
+struct SvgdTileArgs {
+  float *particles;        // (n_local, D) this rank's rows (updated)
+  const float *all;        // (M, D) snapshot the kernel matrix is evaluated on
+  float *adam_m, *adam_v;  // (n_local, D)
+  const float *grad;       // (n_local, D)
+  long long D;
+  int M, n_local, row0;
+  float lr_t, gamma;
+  double *part;            // (n_local, nblk, 64) partial squared distances
+  int nblk;
+  double *kmat;            // (n_local, 64) kernel values (0 past M)
+  float *ksum;             // (n_local)
+};
+
+__global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
+  __shared__ float xs[PYZ_SV_E][64];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  // pair blocks: rectangular (local rows x all particles) for a shard; for the whole matrix d_ij = d_ji
+  // bit for bit, so only the 136 blocks with ti <= tj are computed (threads 0 .. 135) and mirrored
+  const bool whole = g.n_local == g.M && g.row0 == 0;
+  int ti = t >> 4, tj = t & 15;
+  bool active = 4 * ti < g.n_local;
+  if (whole) {
+    int rem = t;
+    ti = 0;
+    while (ti < 16 && rem >= 16 - ti) {
+      rem -= 16 - ti;
+      ++ti;
+    }
+    tj = ti + rem;
+    active = ti < 16 && 4 * tj < g.M;  // (ti <= tj: the row block is inside the matrix too)
+    if (!active) ti = tj = 0;
+  }
+  const long long base = (long long)blockIdx.x * PYZ_SV_R;
+  const bool vec_ok = (g.D % 4 == 0);
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int ps = 0; ps < PYZ_SV_R / PYZ_SV_E; ++ps) {
+    const long long e0 = base + (long long)ps * PYZ_SV_E;
+    if (e0 >= g.D) break;  // uniform
+    // lane = particle: each lane brings 8 x 16 bytes of its row (wave w: elements 32 w .. 32 w + 31 of the slab)
+    {
+      const float *row = g.all + (long long)min(l, g.M - 1) * g.D;
+      float4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long long d = e0 + 32 * w + 4 * q;
+        if (l < g.M && vec_ok && d + 3 < g.D) {
+          v[q] = *reinterpret_cast<const float4 *>(row + d);
+        } else {
+          v[q].x = (l < g.M && d + 0 < g.D) ? row[d + 0] : 0.0f;
+          v[q].y = (l < g.M && d + 1 < g.D) ? row[d + 1] : 0.0f;
+          v[q].z = (l < g.M && d + 2 < g.D) ? row[d + 2] : 0.0f;
+          v[q].w = (l < g.M && d + 3 < g.D) ? row[d + 3] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = 32 * w + 4 * q;
+        xs[e + 0][l] = v[q].x;
+        xs[e + 1][l] = v[q].y;
+        xs[e + 2][l] = v[q].z;
+        xs[e + 3][l] = v[q].w;
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int e = 0; e < PYZ_SV_E; ++e) {
+        const float4 xi = *reinterpret_cast<const float4 *>(&xs[e][g.row0 + 4 * ti]);
+        const float4 xj = *reinterpret_cast<const float4 *>(&xs[e][4 * tj]);
+        const double di[4] = {(double)xi.x, (double)xi.y, (double)xi.z, (double)xi.w};
+        const double dj[4] = {(double)xj.x, (double)xj.y, (double)xj.z, (double)xj.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = di[a] - dj[b];
+            acc[a][b] += df * df;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double *o = g.part + ((long long)(4 * ti + a) * g.nblk + blockIdx.x) * 64 + 4 * tj;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) o[b] = acc[a][b];
+    }
+    if (whole && ti != tj) {  // the mirrored block: rows 4 tj .. 4 tj + 3 < M (M is a multiple of 4 here)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double *o = g.part + ((long long)(4 * tj + b) * g.nblk + blockIdx.x) * 64 + 4 * ti;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) o[a] = acc[a][b];
+      }
+    }
+  }
+}
+
+// one workgroup per local row: d_ij = sum of the row's partials (four interleaved slices of the blocks, each
+// in block order, combined in a fixed order), K_ij, sum_j K_ij (float, j ascending)
+__global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g) {
+  __shared__ double sl[4][64];
+  const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const double *pp = g.part + (long long)il * g.nblk * 64 + j;
+  double s = 0.0;
+  for (int b0 = q; b0 < g.nblk; b0 += 32) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  sl[q][j] = s;
+  __syncthreads();
+  if (q != 0) return;
+  const double d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
+  const double k = j < g.M ? exp(-(double)g.gamma * d) : 0.0;
+  g.kmat[il * 64 + j] = k;
+  float ks = 0.0f;
+  for (int u = 0; u < g.M; ++u) ks += (float)__shfl(k, u, 64);
+  if (j == 0) g.ksum[il] = ks;
+}
+
+// phi_i and the legacy Adam step (the arithmetic of k_svgd_update) for every local row, one element per thread
+__global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g) {
+  extern __shared__ double kd[];  // [n_local][64] kernel values, then n_local floats: their row sums
+  float *ksl = reinterpret_cast<float *>(kd + (size_t)g.n_local * 64);
+  for (int e = threadIdx.x; e < g.n_local * 64; e += 256) kd[e] = g.kmat[e];
+  for (int e = threadIdx.x; e < g.n_local; e += 256) ksl[e] = g.ksum[e];
+  __syncthreads();
+  const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (d >= g.D) return;
+  double xj[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) xj[j] = j < g.M ? (double)g.all[(long long)j * g.D + d] : 0.0;
+  for (int il = 0; il < g.n_local; ++il) {
+    const int i = g.row0 + il;
+    const double *kr = kd + il * 64;
+    const float xi = g.all[(long long)i * g.D + d];
+    // every j, in order: a vanished kernel value or j == i adds an exact zero (k_svgd_update skips those
+    // rows to save their reads; here the rows are already in registers)
+    const double xid = (double)xi;
+    double rep = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) rep += kr[j] * (xid - xj[j]);
+    rep *= 2.0 * (double)g.gamma;
+    const long long o = (long long)il * g.D + d;
+    const float phi = (ksl[il] * g.grad[o] + (float)rep) / (float)g.M;
+    float m = g.adam_m[o], v = g.adam_v[o];
+    m = m + (phi - m) * (1.0f - 0.9f);
+    v = v + (phi * phi - v) * (1.0f - 0.999f);
+    g.adam_m[o] = m;
+    g.adam_v[o] = v;
+    g.particles[o] = g.particles[o] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+  }
+}
+
 // d_loss[0] = sum_i loss_i / M   (SVGD.py:125)
 __global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

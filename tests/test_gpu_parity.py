@@ -445,6 +445,32 @@ def test_svgd_jacobi_shard_equals_whole(eng):
     plan.close()
 
 
+def test_svgd_jacobi_tiled_sweep(eng):
+    """Local rows in multiples of 4 run the all-rows-at-once kernels (k_svgd_dist_tile / kmat / update_tile):
+    8 particles against the oracle, and rows [4, 8) as a shard == the same rows of the whole-matrix step."""
+    spec, n = SPECS["wide3"]
+    x, y, _ = make(spec, n, seed=55)
+    D = spec.n_params
+    M = 8
+    parts = (np.random.default_rng(56).normal(size=(M, D)) * 0.05).astype(np.float32)   # close together: K far from I
+    st = o_svgd.SVGDState(parts)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=M)
+    p = dev(parts)
+    am, av = torch.zeros((M, D), device="cuda"), torch.zeros((M, D), device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    for t in range(1, 4):
+        if t == 3:   # the third step also as a shard of rows [4, 8)
+            shard, sm_, sv_ = p[4:].clone(), am[4:].clone(), av[4:].clone()
+            plan.svgd_step(shard, p.clone(), 4, sm_, sv_, dev(x), ydev(spec, y), 0.05, 1.0, t, loss, sweep="jacobi")
+        plan.svgd_step(p, p.clone(), 0, am, av, dev(x), ydev(spec, y), 0.05, 1.0, t, loss, sweep="jacobi")
+        out = o_svgd.svgd_step(st, x, y, spec, 0.05, 1.0, sweep="jacobi")
+        close(loss, [out["loss"]], what="loss")
+    close(p, st.particles, what="particles", rel=2e-4)
+    close(am, st.m, what="adam m", rel=2e-4)
+    assert torch.equal(shard, p[4:]) and torch.equal(sm_, am[4:])       # same kernels, same order: same bits
+    plan.close()
+
+
 # ------------------------------------------------------------------ predict
 def test_predict_matches_oracle(eng):
     for name in ("wide3", "reg3"):
