@@ -1100,7 +1100,8 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     ta.row0 = row0;
     ta.lr_t = a.lr_t;
     ta.gamma = gamma;
-    ta.nblk = cdiv(m->D, PYZ_SV_R);
+    ta.range = PYZ_SV_E * cdiv(m->D, 256LL * PYZ_SV_E);  // one round of workgroups on the 256 CUs
+    ta.nblk = cdiv(m->D, ta.range);
     const size_t n_part = (size_t)n_local * ta.nblk * 64, n_k = (size_t)n_local * 64;
     if ((rc = need_part2(m, n_part + n_k + n_local + 8))) return rc;
     ta.part = full(m)->x.part2;
@@ -1108,7 +1109,7 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     ta.ksum = reinterpret_cast<float *>(ta.kmat + n_k);
     hipLaunchKernelGGL(k_svgd_dist_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
     hipLaunchKernelGGL(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta);
-    hipLaunchKernelGGL(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), sizeof(double) * n_k + sizeof(float) * n_local, st, ta);
+    hipLaunchKernelGGL(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum);
   } else if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
     hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);

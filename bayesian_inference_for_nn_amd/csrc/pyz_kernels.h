@@ -623,7 +623,8 @@ __global__ void __launch_bounds__(256) k_svgd_update(SvgdArgs g) {
 // The per-row kernels above read the (M, D) particle matrix once per ROW: a Jacobi sweep of M = 64
 // rows moves 64 x 40.7 MB twice (distances, update).  With every row updated from the same snapshot
 // the matrix needs to be read once per pass:
-//   k_svgd_dist_tile   a workgroup owns PYZ_SV_R consecutive elements of D, stages 128-element slabs
+//   k_svgd_dist_tile   a workgroup owns `range` consecutive elements of D (a multiple of 128 chosen so that the
+//                      grid is one round of the 256 CUs), stages 128-element slabs
 //                      of ALL particles in LDS ([element][particle]) and accumulates the float64
 //                      squared-distance partials of its 4 x 4 pair blocks (thread (ti, tj): local rows
 //                      4 ti .. + 3 against particles 4 tj .. + 3), the reference's arithmetic
@@ -633,7 +634,6 @@ __global__ void __launch_bounds__(256) k_svgd_update(SvgdArgs g) {
 //                      produces phi_i[d] + the Adam step for every local row i (the formulas and the
 //                      summation order over j of k_svgd_update).
 // Needs M <= 64 and local rows in multiples of 4 starting at a multiple of 4; else the per-row kernels run.
-#define PYZ_SV_R 512   // elements of D per workgroup of k_svgd_dist_tile
 #define PYZ_SV_E 128   // elements staged per pass
 
 struct SvgdTileArgs {
@@ -646,6 +646,7 @@ struct SvgdTileArgs {
   float lr_t, gamma;
   double *part;            // (n_local, nblk, 64) partial squared distances
   int nblk;
+  int range;               // elements of D per workgroup of k_svgd_dist_tile (multiple of PYZ_SV_E)
   double *kmat;            // (n_local, 64) kernel values (0 past M)
   float *ksum;             // (n_local)
 };
@@ -669,14 +670,14 @@ __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
     active = ti < 16 && 4 * tj < g.M;  // (ti <= tj: the row block is inside the matrix too)
     if (!active) ti = tj = 0;
   }
-  const long long base = (long long)blockIdx.x * PYZ_SV_R;
+  const long long base = (long long)blockIdx.x * g.range;
   const bool vec_ok = (g.D % 4 == 0);
   double acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  for (int ps = 0; ps < PYZ_SV_R / PYZ_SV_E; ++ps) {
+  for (int ps = 0; ps < g.range / PYZ_SV_E; ++ps) {
     const long long e0 = base + (long long)ps * PYZ_SV_E;
     if (e0 >= g.D) break;  // uniform
     // lane = particle: each lane brings 8 x 16 bytes of its row (wave w: elements 32 w .. 32 w + 31 of the slab)
@@ -766,31 +767,38 @@ __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g) {
   if (j == 0) g.ksum[il] = ks;
 }
 
-// phi_i and the legacy Adam step (the arithmetic of k_svgd_update) for every local row, one element per thread
-__global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g) {
-  extern __shared__ double kd[];  // [n_local][64] kernel values, then n_local floats: their row sums
-  float *ksl = reinterpret_cast<float *>(kd + (size_t)g.n_local * 64);
-  for (int e = threadIdx.x; e < g.n_local * 64; e += 256) kd[e] = g.kmat[e];
-  for (int e = threadIdx.x; e < g.n_local; e += 256) ksl[e] = g.ksum[e];
-  __syncthreads();
+// phi_i and the legacy Adam step (the arithmetic of k_svgd_update) for every local row, one element per thread.
+// The kernel values are wave-uniform: they come through the scalar cache (restrict-qualified kernel
+// arguments, so the compiler may use s_load) and feed the float64 FMAs as SGPR operands; reading them
+// from LDS cost one 512-byte broadcast per (row, j) and made the kernel LDS-bound (222 us).
+__global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const double *__restrict__ kmat,
+                                                          const float *__restrict__ ksum) {
   const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
   if (d >= g.D) return;
+  // x_j[d] of every particle: all 64 loads are issued before the first use (rows past M repeat the last one
+  // and are zeroed; a load under `if (j < M)` would wait for its own round trip, 64 times in a row)
+  float xf[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) xf[j] = g.all[(long long)min(j, g.M - 1) * g.D + d];
   double xj[64];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) xj[j] = j < g.M ? (double)g.all[(long long)j * g.D + d] : 0.0;
+  for (int j = 0; j < 64; ++j) xj[j] = j < g.M ? (double)xf[j] : 0.0;
   for (int il = 0; il < g.n_local; ++il) {
     const int i = g.row0 + il;
-    const double *kr = kd + il * 64;
+    const double *kr = kmat + il * 64;
     const float xi = g.all[(long long)i * g.D + d];
     // every j, in order: a vanished kernel value or j == i adds an exact zero (k_svgd_update skips those
     // rows to save their reads; here the rows are already in registers)
+    // four interleaved partial sums (j mod 4), combined in a fixed order: a single chain of 64 dependent
+    // float64 FMAs would run at their latency, not their rate
     const double xid = (double)xi;
-    double rep = 0.0;
+    double r4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 64; ++j) rep += kr[j] * (xid - xj[j]);
+    for (int j = 0; j < 64; ++j) r4[j & 3] += kr[j] * (xid - xj[j]);
+    double rep = (r4[0] + r4[1]) + (r4[2] + r4[3]);
     rep *= 2.0 * (double)g.gamma;
     const long long o = (long long)il * g.D + d;
-    const float phi = (ksl[il] * g.grad[o] + (float)rep) / (float)g.M;
+    const float phi = (ksum[il] * g.grad[o] + (float)rep) / (float)g.M;
     float m = g.adam_m[o], v = g.adam_v[o];
     m = m + (phi - m) * (1.0f - 0.9f);
     v = v + (phi * phi - v) * (1.0f - 0.999f);
