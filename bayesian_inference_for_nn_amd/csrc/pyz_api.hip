@@ -80,6 +80,30 @@ int check_call(const pyz_mlp *m, int P, int batch) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
+            int slot0 = 0) {
+  m->pend_on = false;
+  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// eager steps: no launch for the scalars -- the first kernel of the fused step carries them (pyz_ctl_first)
+void set_ctl_lazy(pyz_mlp *m, int batch, float lr, long long n) {
+  m->pend = StepCtl{};
+  m->pend.batch = batch;
+  m->pend.lr = lr;
+  m->pend.n = n;
+  m->pend_on = true;
+}
+
+void flush_ctl(pyz_mlp *m, hipStream_t st) {
+  if (!m->pend_on) return;
+  m->pend_on = false;
+  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl, m->pend.batch, m->pend.lr, m->pend.n, m->pend.row_off, m->pend.i,
+                     m->pend.slot0);
+}
+
 // forward over all layers; activations land in m->act[l]
 void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
                     const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st,
@@ -107,6 +131,11 @@ void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, c
     g.act = m->acts[l];
     g.vec = (g.K % 8 == 0) && aligned16(g.in) ? 1 : 0;
     g.ctl = ctl;
+    if (l == 0 && m->pend_on && ctl == m->ctl) {  // first kernel of an eager step: carries the step scalars
+      g.init = m->pend;
+      g.init_on = 1;
+      m->pend_on = false;
+    }
     pyz_launch_fwd(g, grid_batch, P, st);
   }
 }
@@ -225,6 +254,11 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   g.prev_pstride = (long long)m->max_batch * g.K;
   g.part = m->part;
   g.ctl = ctl;
+  if (m->pend_on && ctl == m->ctl) {  // no hidden layer: the head is the first kernel of the eager step
+    g.init = m->pend;
+    g.init_on = 1;
+    m->pend_on = false;
+  }
   // one wave per batch row when the lane-resident operands fit (UT units x NP classes per lane)
   static const int rows_on = pyz_env_int("PYZ_HEAD_ROWS", 1);
   const int UT = g.K <= 64 ? 1 : g.K <= 256 ? 4 : g.K <= 512 ? 8 : g.K <= 1024 ? 16 : 0;
@@ -335,17 +369,11 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
     if (ev) (void)hipEventRecord(ev[3], st);
     return;
   }
+  flush_ctl(m, st);
   launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st);
   launch_loss(m, P, y, row_idx, grid_batch, ctl, want_grad, st);
   m->cur_nblk = loss_nblk(m, grid_batch);
   if (want_grad) launch_backward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, upd.grad, st);
-}
-
-int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
-            int slot0 = 0) {
-  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
-  PYZ_LAUNCH_CHECK();
-  return PYZ_OK;
 }
 
 int check_loss_combo(const pyz_mlp *m) {
@@ -488,7 +516,7 @@ int pyz_mlp_loss_grad(pyz_mlp *m, const float *d_theta, int P, const float *d_x,
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_theta || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   hipStream_t st = as_stream(stream);
-  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, 0.0f, 0);
   WgradArgs u{};
   u.mode = PYZ_UPD_NONE;
   u.grad = d_grad;
@@ -509,7 +537,7 @@ int pyz_sgd_step(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, 
   const bool fused = can_fuse(m);
   if (!fused && (rc = need_grad(m, 1))) return rc;
   hipStream_t st = as_stream(stream);
-  if ((rc = set_ctl(m, 0, batch, lr, 0, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, lr, 0);
   WgradArgs u{};
   if (fused) {  // the update runs in the epilogue of the weight-gradient kernel
     u.mode = PYZ_UPD_SGD;
@@ -540,7 +568,7 @@ int pyz_swag_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, f
   const bool fused = can_fuse(m);
   if (!fused && (rc = need_grad(m, 1))) return rc;
   hipStream_t st = as_stream(stream);
-  if ((rc = set_ctl(m, 0, batch, lr, n, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, lr, n);
   WgradArgs u{};
   if (fused) {
     u.mode = PYZ_UPD_SWAG;
@@ -620,7 +648,7 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
   if (n < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
   if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   hipStream_t st = as_stream(stream);
-  if ((rc = set_ctl(m, 0, batch, lr, n, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, lr, n);
   launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, batch, 0, false, 0, seed, d_unit_noise, d_loss, st);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -770,7 +798,7 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   const int nblk_kl = cdiv(cdiv(m->D, 4), 256);
   if ((rc = need_part2(m, nblk_kl))) return rc;
   hipStream_t st = as_stream(stream);
-  if ((rc = set_ctl(m, 0, batch, lr, step, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, lr, step);
   BbbArgs a{};
   a.mu = d_mu;
   a.rho = d_rho;

@@ -58,6 +58,15 @@ __device__ unsigned long long pyz_dbg_buf[PYZ_STAMP_KERNELS][PYZ_STAMP_BLOCKS][P
 // instead of exec-masked vector compares
 __device__ __forceinline__ int pyz_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// Eager step entry points do not spend a launch on the step scalars: the FIRST kernel of the step gets
+// them by value (`init`), uses them, and its first thread publishes them in the device StepCtl for the
+// kernels behind it (which start after that kernel has ended).
+__device__ __forceinline__ StepCtl pyz_ctl_first(const StepCtl *ctl, const StepCtl &init, const int on) {
+  if (!on) return *ctl;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *const_cast<StepCtl *>(ctl) = init;
+  return init;
+}
+
 // ---------------------------------------------------------------- host errors
 inline std::string &pyz_err_slot() {
   static thread_local std::string s;
@@ -113,6 +122,8 @@ struct pyz_mlp {
   int cur_nblk = 0;                          // number of loss partials the last loss launch wrote per particle
   float *scal = nullptr;                     // small device scalars
   StepCtl *ctl = nullptr;                    // device StepCtl
+  StepCtl pend{};                            // eager steps: the scalars of the step about to be launched ...
+  bool pend_on = false;                      // ... not yet on the device: the first kernel of the step publishes them
   int32_t *tab_bs = nullptr;                 // per-run tables (device)
   float *tab_lr = nullptr;
   int tab_cap = 0;

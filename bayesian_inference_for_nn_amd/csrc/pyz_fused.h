@@ -39,6 +39,8 @@ struct HeadArgs {
   double *part;              // (P, nblk) per-workgroup sums of the row losses
   int nblk;
   const StepCtl *ctl;
+  StepCtl init;              // the step scalars by value when the head is the first kernel of an eager step (L == 1)
+  int init_on;
 };
 
 // lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
@@ -60,13 +62,14 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63, r = l & 31, h = l >> 5;
   float *red = lds, *zt = lds + S * 1024, *dt = zt + 32 * 33;
   double *lsum = reinterpret_cast<double *>(dt + 32 * 33);  // 4 doubles (8-byte aligned: S*4096 + 8448 bytes)
-  const int batch = g.ctl->batch, p = blockIdx.y, m0 = blockIdx.x * 32;
+  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
+  const int batch = ctl.batch, p = blockIdx.y, m0 = blockIdx.x * 32;
   if (m0 >= batch) {
     if (threadIdx.x == 0) g.part[p * g.nblk + blockIdx.x] = 0.0;
     return;
   }
   const int K = g.K, N = g.N;
-  const int32_t *idx = g.row_idx ? g.row_idx + g.ctl->row_off : nullptr;
+  const int32_t *idx = g.row_idx ? g.row_idx + ctl.row_off : nullptr;
   // loss-phase inputs (threads 0..255: row = t >> 3), fetched now so their latency hides behind phase 1
   const int lrow = threadIdx.x >> 3, lsub = threadIdx.x & 7;
   const int lmm = m0 + lrow;
@@ -261,7 +264,8 @@ template <int UT, int NP>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
   const int w = pyz_wave_id(), l = threadIdx.x & 63;
-  const int batch = g.ctl->batch, p = blockIdx.y;
+  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
+  const int batch = ctl.batch, p = blockIdx.y;
   const int m = blockIdx.x * 4 + w;  // this wave's batch row (scalar)
   if (m >= batch) {
     if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   }
   const int K = g.K, N = g.N;
   long long yrow = m;
-  if (g.row_idx) yrow = g.row_idx[g.ctl->row_off + m];
+  if (g.row_idx) yrow = g.row_idx[ctl.row_off + m];
   const float *hp = g.hin + p * g.hin_pstride + (g.gather_hin ? yrow : (long long)m) * g.lda;
   const float *wl = g.theta + p * g.theta_pstride + g.w_off;
   // Operands through buffer descriptors (per-lane byte offsets, range checked against the byte count):

@@ -45,6 +45,8 @@ struct DenseArgs {
   const StepCtl *ctl;         // batch (rows) and row-index offset of this step
   const int32_t *row_idx;     // optional gather of `in` rows (layer 0 only)
   float *gather_out;          // optional (max_batch, K): contiguous copy of the gathered rows (forward, layer 0)
+  StepCtl init;               // forward only: the step scalars by value when this is the first kernel of an eager step
+  int init_on;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids
@@ -298,7 +300,8 @@ __global__ void k_dense_fwd(DenseArgs g) {
   PYZ_STAMP(0, 0);
   const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
-  const int batch = g.ctl->batch;
+  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
+  const int batch = ctl.batch;
   const int tiles_n = (g.N + 31) >> 5;
   const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
@@ -307,7 +310,7 @@ __global__ void k_dense_fwd(DenseArgs g) {
   const int K = g.K, N = g.N;
   const int m = min(m0 + r, batch - 1), n = min(n0 + r, N - 1);  // clamped: rows/cols past the edge are never stored
   long long row = m;
-  if (g.row_idx) row = g.row_idx[g.ctl->row_off + m];
+  if (g.row_idx) row = g.row_idx[ctl.row_off + m];
   const float *ap = g.in + p * g.in_pstride + row * g.lda;
   const float *wl = g.theta + p * g.theta_pstride + g.w_off;
   f32x16 acc = {0};
