@@ -62,9 +62,22 @@ __device__ __forceinline__ int pyz_wave_id() { return __builtin_amdgcn_readfirst
 // them by value (`init`), uses them, and its first thread publishes them in the device StepCtl for the
 // kernels behind it (which start after that kernel has ended).
 __device__ __forceinline__ StepCtl pyz_ctl_first(const StepCtl *ctl, const StepCtl &init, const int on) {
-  if (!on) return *ctl;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *const_cast<StepCtl *>(ctl) = init;
-  return init;
+  if (on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *const_cast<StepCtl *>(ctl) = init;
+  // Both sources are wave-uniform and should stay scalar.  The by-value fields pass through an empty asm:
+  // without it the compiler rewrites "select between two loaded values" as "load through a selected
+  // address", and that address is a flat VGPR pointer -- every field becomes a vector load.
+  int ib = init.batch, ii = init.i, is0 = init.slot0;
+  float il = init.lr;
+  long long in_ = init.n, iro = init.row_off;
+  asm volatile("" : "+s"(ib), "+s"(ii), "+s"(is0), "+s"(il), "+s"(in_), "+s"(iro));
+  StepCtl c;
+  c.batch = on ? ib : ctl->batch;
+  c.lr = on ? il : ctl->lr;
+  c.n = on ? in_ : ctl->n;
+  c.row_off = on ? iro : ctl->row_off;
+  c.i = on ? ii : ctl->i;
+  c.slot0 = on ? is0 : ctl->slot0;
+  return c;
 }
 
 // ---------------------------------------------------------------- host errors

@@ -248,7 +248,8 @@ def test_sgld_step_injected_and_device_noise(eng, name):
 def test_sgld_run_matches_stepwise_oracle(eng, use_graph):
     spec = o_mlp.MLPSpec((24, 16, 4), ("relu", "softmax"), "scce")
     rng = np.random.default_rng(21)
-    N, B, n_steps = 150, 64, 19          # 150 rows, batch 64 -> batches 64, 64, 22 per epoch
+    # 150 rows, batch 64 -> batches 64, 64, 22 per epoch; with the graph: two 32-step replays + 6 eager steps
+    N, B, n_steps = 150, 64, (70 if use_graph else 19)
     x = rng.normal(size=(N, 24)).astype(np.float32)
     y = rng.integers(0, 4, size=N).astype(np.int32)
     theta = (rng.normal(size=spec.n_params) * 0.3).astype(np.float32)
