@@ -66,7 +66,8 @@ def load():
     if _lib is not None:
         return _lib
     try:
-        path = _build.build()
+        # PYZ_LIB_OVERRIDE: diagnostics only (A/B runs of an alternative build of the SAME library)
+        path = os.environ.get("PYZ_LIB_OVERRIDE") or _build.build()
     except Exception as e:  # no hipcc / compile error: no fallback exists
         if os.path.exists(_build.LIB):
             path = _build.LIB
