@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 DIMS = (784, 200, 10)
 BATCH = 1024
+GRAPH_STEPS = 32          # steps per captured graph in csrc/pyz_api.hip (PYZ_GRAPH_STEPS)
 N_ROWS = 48_000
 LR_UPPER, LR_LOWER, LR_GAMMA = 0.01, 0.003, 0.99      # reference tests/unittest2.py:73
 SEED = 2024
@@ -160,6 +161,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # One-time setup, like compilation: the library captures its 32-step hipGraph the first time a run is long
+    # enough.  Prime it here on the real buffers (their addresses are baked into the graph) and put the chain
+    # state back, so that neither the warm-up nor the timed region contains the capture when W < 32.
+    if use_graph and total >= GRAPH_STEPS:
+        saved = (theta.clone(), mean.clone(), sq_mean.clone())
+        run(0, GRAPH_STEPS)
+        torch.cuda.synchronize()
+        for dst, src in zip((theta, mean, sq_mean), saved):
+            dst.copy_(src)
+        del saved
     if args.warmup > 0:
         run(0, args.warmup)
     fence()
