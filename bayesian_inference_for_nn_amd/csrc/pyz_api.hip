@@ -594,11 +594,11 @@ int pyz_swag_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, f
 // ---------------------------------------------------------------- L2/L3
 static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
-                             uint64_t seed, const float *unit_noise, float *loss, hipStream_t st) {
+                             uint64_t seed, const float *unit_noise, float *loss, hipStream_t st, int mode = PYZ_UPD_SGLD) {
   const StepCtl *ctl = m->ctl + slot;
   if (can_fuse(m)) {
     WgradArgs u{};
-    u.mode = PYZ_UPD_SGLD;
+    u.mode = mode;  // PYZ_UPD_SGLD, or PYZ_UPD_SGD for the chained SGD run (fused path only)
     u.theta = theta;
     u.mean = mean;
     u.sq_mean = sq;
@@ -657,8 +657,13 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
 static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
                          const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
                          int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream,
-                         hipEvent_t *events /* optional: 4 per step, recorded around the kernels (eager only) */) {
+                         hipEvent_t *events /* optional: 4 per step, recorded around the kernels (eager only) */,
+                         int mode = PYZ_UPD_SGLD) {
   if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (mode == PYZ_UPD_SGD) {
+    if (!can_fuse(m)) return pyz_fail(PYZ_E_INVALID, "the chained SGD run needs a last layer of at most 32 units");
+    d_mean = d_sq_mean = d_theta;  // not touched in this mode
+  }
   int rc = check_loss_combo(m);
   if (rc) return rc;
   if (n_steps <= 0) return pyz_fail(PYZ_E_INVALID, "n_steps must be positive");
@@ -720,14 +725,14 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     mix((unsigned long long)(uintptr_t)d_sq_mean); mix((unsigned long long)(uintptr_t)d_x);
     mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
     mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
-    mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G);
+    mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G); mix((unsigned long long)mode);
     if (!m->graph_exec || m->graph_key != key) {
       if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
       if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
       PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
       for (int k = 0; k < G; ++k)
         launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
-                         nullptr, d_losses, st);
+                         nullptr, d_losses, st, mode);
       hipGraph_t gr = nullptr;
       PYZ_HIP(hipStreamEndCapture(st, &gr));
       m->graph = gr;
@@ -739,7 +744,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   for (; s < n_steps; ++s) {
     m->probe = events ? events + 4 * (size_t)s : nullptr;
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
-                     d_losses, st);
+                     d_losses, st, mode);
   }
   m->probe = nullptr;
   PYZ_LAUNCH_CHECK();
@@ -751,6 +756,15 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
                  int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream) {
   return sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, seed,
                        d_losses, use_graph, stream, nullptr);
+}
+
+// The SGD train loop (SGD.py:42-69 inside Optimizer.py:121-134) as one device-resident run: the launch sequence
+// of pyz_sgld_run with the plain update in the weight-gradient epilogue (no noise, no moments).
+int pyz_sgd_run(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, const int32_t *d_row_idx,
+                const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t slot0, float *d_losses, int use_graph,
+                void *stream) {
+  return sgld_run_impl(m, d_theta, d_theta, d_theta, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, 0, slot0, 0, d_losses,
+                       use_graph, stream, nullptr, PYZ_UPD_SGD);
 }
 
 // Measurement: n_steps eager SGLD steps with HIP events around the kernels of every step, on the

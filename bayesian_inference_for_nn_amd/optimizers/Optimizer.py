@@ -203,9 +203,12 @@ class Optimizer(ABC):
         B = self._plan.max_batch
         table = np.zeros((n_steps, B), dtype=np.int32)
         sizes = []
+        self._plan_epoch_starts = []                 # steps of this plan that opened a new epoch
         host_perm = None if self._perm_dev is None else self._perm_dev.cpu().numpy()
         for s in range(n_steps):
             if host_perm is None or self._pos >= self._training_dataset_cardinality:
+                if host_perm is not None:
+                    self._plan_epoch_starts.append(s)
                 self._new_epoch()
                 host_perm = self._perm_dev.cpu().numpy()
             b = min(int(self._batch_size), self._training_dataset_cardinality - self._pos)

@@ -55,6 +55,48 @@ class SGD(Optimizer):
         self._n += 1
         return DeviceScalar(self._running_dev.clone(), 0, 1.0 / self._seen_batches)
 
+    def _train_resident(self, nb_iterations: int) -> bool:
+        """verbose=False: all steps in device-resident runs (hipGraph replay, no per-step host work).  The
+        "mean" of SGD.py:78-84 is the weights after the last step whose count is a multiple of `frequency`:
+        the run is cut there, the weights copied, and the rest follows."""
+        import torch
+        from .._lib import PyzError
+        if nb_iterations <= 0:
+            return True
+        idx, sizes = self._batch_plan(nb_iterations)
+        lrs = [float(self._lr)] * nb_iterations
+        losses = torch.zeros(nb_iterations, device="cuda")
+        freq = int(self._frequency)
+        hits = [s for s in range(nb_iterations) if (self._n + s) % freq == 0]
+        cut = hits[-1] + 1 if hits else 0             # steps [0, cut) end with the last "mean <- weights"
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream):
+                if cut > 0:
+                    self._plan.sgd_run(self._theta, self._x_dev, self._y_dev, idx, sizes[:cut], lrs[:cut], losses)
+                    self._mean_dev.copy_(self._theta)
+                if cut < nb_iterations:
+                    self._plan.sgd_run(self._theta, self._x_dev, self._y_dev, idx, sizes[cut:], lrs[cut:], losses, slot0=cut)
+        except PyzError:                              # shapes the fused step does not take: per-step loop
+            if cut > 0:
+                raise
+            return False
+        torch.cuda.current_stream().wait_stream(stream)
+        # epoch bookkeeping of step() (SGD.py:45-60) for the steps just run
+        last_epoch = self._plan_epoch_starts[-1] if self._plan_epoch_starts else None
+        if last_epoch is None:
+            self._seen_batches += nb_iterations
+            self._running_dev += losses.sum()
+        else:
+            self._epoch_num += len(self._plan_epoch_starts)
+            self._seen_batches = nb_iterations - last_epoch
+            self._running_dev.copy_(losses[last_epoch:].sum().reshape(1))
+        self._loss_dev.copy_(losses[-1:])
+        self._n += nb_iterations
+        self.last_losses = losses
+        return True
+
     def result(self) -> BayesianModel:
         model = BayesianModel(self._model_config)
         mean = self._mean_dev.cpu().numpy()

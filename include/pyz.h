@@ -124,6 +124,14 @@ int pyz_sgld_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, 
                  const float *h_lr, int n_steps, int64_t n0, int64_t slot0, uint64_t seed,
                  float *d_losses, int use_graph, void *stream);
 
+/* Device-resident multi-step SGD (SGD.py:42-69 under the train loop of Optimizer.py:121-134): the
+ * arguments of pyz_sgld_run without the moment vectors, count and seed; step s applies
+ * theta <- theta - h_lr[s] * grad on its batch and writes the batch loss to d_losses[slot0+s].
+ * Needs the fused step (last layer of at most 32 units). */
+int pyz_sgd_run(pyz_mlp *mlp, float *d_theta, const float *d_x, const void *d_y,
+                const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr,
+                int n_steps, int64_t slot0, float *d_losses, int use_graph, void *stream);
+
 /* Measurement (bench.py roofline leg): n_steps eager SGLD steps, same arguments and effect as
  * pyz_sgld_run, with HIP events recorded on `stream` around the kernels of every step.
  * h_avg_us[3] = average in-pipeline duration in microseconds (launch gap included) of

@@ -263,3 +263,28 @@ def test_swag_moons_posterior_and_store_load(tmp_path):
     back = BayesianModel.load(str(tmp_path / "swag"))
     assert [type(d).__name__ for d in back._distributions] == ["MultivariateNormalDiagPlusLowRank"] * 2
     np.testing.assert_allclose(back._distributions[1]._D, bm._distributions[1]._D, rtol=1e-6)
+
+
+def test_sgd_quiet_train_is_the_step_loop():
+    """verbose=False runs the whole SGD train loop on the device (pyz_sgd_run, graph replay, cut at the last
+    `frequency` hit): same weights, same "mean", same epoch bookkeeping as the per-step loop."""
+    def make():
+        ds = moons_dataset(seed=5)
+        start = model_from_json(MOONS_JSON)
+        start.reset_glorot(np.random.default_rng(9))
+        opt = SGD()
+        return opt, ds, start
+    n_it = 75                                               # 400 training rows, batch 64: 7 batches per epoch
+    a, ds, start = make()
+    a.compile(HyperParameters(lr=0.05, frequency=4, batch_size=64), MOONS_JSON, ds, verbose=False, starting_model=start, seed=11)
+    a.train(n_it)
+    b, ds2, start2 = make()
+    b.compile(HyperParameters(lr=0.05, frequency=4, batch_size=64), MOONS_JSON, ds2, verbose=False, starting_model=start2, seed=11)
+    for _ in range(n_it):
+        last = b.step()
+    assert a._n == b._n == n_it and a._epoch_num == b._epoch_num and a._seen_batches == b._seen_batches
+    np.testing.assert_allclose(a._theta.cpu().numpy(), b._theta.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a._mean_dev.cpu().numpy(), b._mean_dev.cpu().numpy(), rtol=0, atol=1e-6)
+    assert not torch.equal(a._mean_dev, a._theta)            # 75 steps: the last "mean <- weights" was at count 72
+    np.testing.assert_allclose(float(a._running_dev), float(b._running_dev), rtol=1e-5)
+    assert a.last_losses.shape == (n_it,) and abs(float(a._loss_dev) - float(b._loss_dev)) < 1e-6
