@@ -41,6 +41,8 @@ SIGNATURES = {
     "pyz_sgld_run": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _i64, _i64, _u64,
                                _p, C.c_int, _p]),
     "pyz_sgd_run": (C.c_int, [_p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _i64, _p, C.c_int, _p]),
+    "pyz_swag_run": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int,
+                               _i64, _i64, _p, C.c_int, _p]),
     "pyz_sgld_profile": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _i64, _i64, _u64,
                                    _p, C.POINTER(_f), _p]),
     "pyz_bbb_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _f, _f, _f, _p, _p, _i64, _u64, _p, _p, _p]),

@@ -592,13 +592,25 @@ int pyz_swag_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, f
 }
 
 // ---------------------------------------------------------------- L2/L3
+struct SwagChain {  // chained SWAG run: the (k, D) deviation matrix and the two hyper-parameters its bookkeeping needs
+  float *dev;
+  int k, freq;
+};
+
 static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
-                             uint64_t seed, const float *unit_noise, float *loss, hipStream_t st, int mode = PYZ_UPD_SGLD) {
+                             uint64_t seed, const float *unit_noise, float *loss, hipStream_t st, int mode = PYZ_UPD_SGLD,
+                             const SwagChain *swag = nullptr) {
   const StepCtl *ctl = m->ctl + slot;
   if (can_fuse(m)) {
     WgradArgs u{};
-    u.mode = mode;  // PYZ_UPD_SGLD, or PYZ_UPD_SGD for the chained SGD run (fused path only)
+    u.mode = mode;  // PYZ_UPD_SGLD, or PYZ_UPD_SGD / PYZ_UPD_SWAG for the chained SGD / SWAG runs (fused path only)
+    if (swag) {
+      u.swag_freq = swag->freq;
+      u.swag_k = swag->k;
+      u.dev_base = swag->dev;
+      u.dev_stride = m->D;
+    }
     u.theta = theta;
     u.mean = mean;
     u.sq_mean = sq;
@@ -658,12 +670,11 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
                          const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
                          int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream,
                          hipEvent_t *events /* optional: 4 per step, recorded around the kernels (eager only) */,
-                         int mode = PYZ_UPD_SGLD) {
+                         int mode = PYZ_UPD_SGLD, const SwagChain *swag = nullptr) {
   if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
-  if (mode == PYZ_UPD_SGD) {
-    if (!can_fuse(m)) return pyz_fail(PYZ_E_INVALID, "the chained SGD run needs a last layer of at most 32 units");
-    d_mean = d_sq_mean = d_theta;  // not touched in this mode
-  }
+  if (mode != PYZ_UPD_SGLD && !can_fuse(m))
+    return pyz_fail(PYZ_E_INVALID, "the chained SGD / SWAG runs need a last layer of at most 32 units");
+  if (mode == PYZ_UPD_SGD) d_mean = d_sq_mean = d_theta;  // not touched in this mode
   int rc = check_loss_combo(m);
   if (rc) return rc;
   if (n_steps <= 0) return pyz_fail(PYZ_E_INVALID, "n_steps must be positive");
@@ -726,13 +737,14 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
     mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
     mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G); mix((unsigned long long)mode);
+    if (swag) { mix((unsigned long long)(uintptr_t)swag->dev); mix((unsigned long long)swag->k); mix((unsigned long long)swag->freq); }
     if (!m->graph_exec || m->graph_key != key) {
       if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
       if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
       PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
       for (int k = 0; k < G; ++k)
         launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
-                         nullptr, d_losses, st, mode);
+                         nullptr, d_losses, st, mode, swag);
       hipGraph_t gr = nullptr;
       PYZ_HIP(hipStreamEndCapture(st, &gr));
       m->graph = gr;
@@ -744,7 +756,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   for (; s < n_steps; ++s) {
     m->probe = events ? events + 4 * (size_t)s : nullptr;
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
-                     d_losses, st, mode);
+                     d_losses, st, mode, swag);
   }
   m->probe = nullptr;
   PYZ_LAUNCH_CHECK();
@@ -765,6 +777,18 @@ int pyz_sgd_run(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, c
                 void *stream) {
   return sgld_run_impl(m, d_theta, d_theta, d_theta, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, 0, slot0, 0, d_losses,
                        use_graph, stream, nullptr, PYZ_UPD_SGD);
+}
+
+// The SWAG train loop (SWAG.py:43-94 inside Optimizer.py:121-134) as one device-resident run.  The moment / deviation
+// bookkeeping follows from the step count on the device: it must have started at count 0 with every step run.
+int pyz_swag_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, float *d_dev, int k, int frequency,
+                 const float *d_x, const void *d_y, const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr,
+                 int n_steps, int64_t n0, int64_t slot0, float *d_losses, int use_graph, void *stream) {
+  if (!d_dev || k < 1 || frequency < 1) return pyz_fail(PYZ_E_INVALID, "bad deviation matrix / k / frequency");
+  if (n0 < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
+  const SwagChain sc{d_dev, k, frequency};
+  return sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, 0, d_losses,
+                       use_graph, stream, nullptr, PYZ_UPD_SWAG, &sc);
 }
 
 // Measurement: n_steps eager SGLD steps with HIP events around the kernels of every step, on the

@@ -413,6 +413,11 @@ struct WgradArgs {
   // SWAG only: dev_row = the (D) row of the deviation matrix that receives theta - mean, or nullptr
   float *dev_row;
   int swag_update;            // moments / deviation updated at this step (n % frequency == 0)
+  // chained SWAG runs (pyz_swag_run): both follow from the step count n -- update when n % swag_freq == 0, into
+  // row min(ceil(n / swag_freq), swag_k - 1) of the (swag_k, dev_stride) deviation matrix dev_base
+  int swag_freq, swag_k;
+  float *dev_base;
+  long long dev_stride;
   // BBB only
   float alpha, prior_mean, prior_rho, bbb_lr;
   const float *pm_vec, *pr_vec;
@@ -436,6 +441,7 @@ struct WgradArgs {
 struct PyzUpdOut {
   float th, mu, sq, dev;
   bool wr_mu, wr_sq, wr_dev;
+  float *dev_row;  // SWAG: the deviation row written at this step
 };
 
 // gv = d loss / d parameter e; th0 / mu0 / sq0 / zz = the state read before (see the modes above)
@@ -445,18 +451,24 @@ __device__ __forceinline__ PyzUpdOut pyz_update_math(const WgradArgs &g, const i
   PyzUpdOut o;
   o.th = o.mu = o.sq = o.dev = 0.0f;
   o.wr_mu = o.wr_sq = o.wr_dev = false;
+  o.dev_row = nullptr;
   if (mode == PYZ_UPD_SGD) {
     o.th = th0 - lr * gv;
   } else if (mode == PYZ_UPD_SWAG) {
     const float th = th0 - lr * gv;
     o.th = th;
-    if (g.swag_update) {
+    const bool upd = g.swag_freq > 0 ? (nstep % g.swag_freq == 0) : (g.swag_update != 0);
+    if (upd) {
       const float fn = (float)nstep, fn1 = fn + 1.0f;
       o.mu = (mu0 * fn + th) / fn1;
       o.sq = (sq0 * fn + th * th) / fn1;
       o.dev = th - o.mu;
       o.wr_mu = o.wr_sq = true;
-      o.wr_dev = g.dev_row != nullptr;
+      // columns are appended until there are k; afterwards the LAST one is replaced (SWAG.py:85-89, as written)
+      o.dev_row = g.swag_freq > 0
+                      ? g.dev_base + min((nstep + g.swag_freq - 1) / g.swag_freq, (long long)g.swag_k - 1) * g.dev_stride
+                      : g.dev_row;
+      o.wr_dev = o.dev_row != nullptr;
     }
   } else if (mode == PYZ_UPD_BBB) {
     // th0 = mu, mu0 = rho, sq0 = the sampled w, zz = eps, gv = d loss / d w   (k_bbb_update's arithmetic)
@@ -492,7 +504,7 @@ __device__ __forceinline__ void pyz_update_store(const WgradArgs &g, const int m
   g.theta[e] = o.th;
   if (o.wr_mu) g.mean[e] = o.mu;
   if (o.wr_sq) g.sq_mean[e] = o.sq;
-  if (o.wr_dev) g.dev_row[e] = o.dev;
+  if (o.wr_dev) o.dev_row[e] = o.dev;
 }
 
 // duties of one spare wave per step that do not depend on the gradient: the loss of this step

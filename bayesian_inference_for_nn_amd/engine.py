@@ -201,6 +201,26 @@ class MLPPlan:
         check(self.lib.pyz_sgd_run(self.h, ptr(theta), ptr(x), ptr(y), ptr(row_idx), bs, lr, n_steps, int(slot0),
                                    ptr(losses_out), 1 if use_graph else 0, _stream()))
 
+    def swag_run(self, theta, mean, sq_mean, dev, frequency, x, y, row_idx, batch_sizes, lrs, n0, losses_out,
+                 use_graph=True, slot0=0):
+        """n = len(batch_sizes) SWAG steps without host work in between; dev is the (k, D) deviation matrix."""
+        n_steps = len(batch_sizes)
+        assert len(lrs) == n_steps and n_steps > 0
+        for t, nm in ((theta, "theta"), (mean, "mean"), (sq_mean, "sq_mean")):
+            _f32(t, (self.D,), nm)
+        _f32(dev, name="dev")
+        assert dev.dim() == 2 and dev.shape[1] == self.D
+        self._check_xy(x, y, row_idx, 1)
+        if slot0 < 0 or row_idx.numel() < (slot0 + n_steps) * self.max_batch or losses_out.numel() < slot0 + n_steps:
+            raise ValueError("row_idx / losses_out too small")
+        if any(int(b) < 1 or int(b) > self.max_batch for b in batch_sizes):
+            raise ValueError("batch size outside the plan")
+        bs = (C.c_int32 * n_steps)(*[int(b) for b in batch_sizes])
+        lr = (C.c_float * n_steps)(*[float(v) for v in lrs])
+        check(self.lib.pyz_swag_run(self.h, ptr(theta), ptr(mean), ptr(sq_mean), ptr(dev), int(dev.shape[0]), int(frequency),
+                                    ptr(x), ptr(y), ptr(row_idx), bs, lr, n_steps, int(n0), int(slot0), ptr(losses_out),
+                                    1 if use_graph else 0, _stream()))
+
     def sgld_profile(self, theta, mean, sq_mean, x, y, row_idx, batch_sizes, lrs, n0, seed, losses_out, slot0=0):
         """n eager steps with HIP events around each kernel; returns average microseconds of
         (forward, head, weight gradient + update) inside the pipeline."""

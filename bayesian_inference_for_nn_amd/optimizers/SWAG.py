@@ -56,6 +56,30 @@ class SWAG(Optimizer):
         self._n += 1
         return DeviceScalar(self._loss_dev.clone(), 0)
 
+    def _train_resident(self, nb_iterations: int) -> bool:
+        """verbose=False: all steps in one device-resident run; the moment / deviation-column bookkeeping is a
+        function of the step count and runs on the device (the chain starts at count 0: compile sets it)."""
+        import torch
+        from .._lib import PyzError
+        if nb_iterations <= 0:
+            return True
+        idx, sizes = self._batch_plan(nb_iterations)
+        losses = torch.zeros(nb_iterations, device="cuda")
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream):
+                self._plan.swag_run(self._theta, self._mean_dev, self._sq_mean_dev, self._dev_rows, self._frequency,
+                                    self._x_dev, self._y_dev, idx, sizes, [float(self._lr)] * nb_iterations, self._n, losses)
+        except PyzError:                              # shapes the fused step does not take: per-step loop
+            return False
+        torch.cuda.current_stream().wait_stream(stream)
+        self._n += nb_iterations
+        self._n_cols = min(self._k, -(-self._n // self._frequency))      # hits among counts 0 .. n - 1
+        self._loss_dev.copy_(losses[-1:])
+        self.last_losses = losses
+        return True
+
     def update_parameters_step(self):
         pass
 

@@ -132,6 +132,16 @@ int pyz_sgd_run(pyz_mlp *mlp, float *d_theta, const float *d_x, const void *d_y,
                 const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr,
                 int n_steps, int64_t slot0, float *d_losses, int use_graph, void *stream);
 
+/* Device-resident multi-step SWAG (SWAG.py:43-94 under the train loop): step s has count n0 + s; when the
+ * count is a multiple of `frequency` the moments are updated and theta - mean goes to row
+ * min(ceil(count / frequency), k - 1) of d_dev (float32 (k, D), row = one column of the reference's
+ * deviation matrix).  The bookkeeping assumes the chain started at count 0 with every step run through
+ * pyz_swag_step / pyz_swag_run.  Needs the fused step. */
+int pyz_swag_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, float *d_dev, int k,
+                 int frequency, const float *d_x, const void *d_y, const int32_t *d_row_idx,
+                 const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
+                 int64_t slot0, float *d_losses, int use_graph, void *stream);
+
 /* Measurement (bench.py roofline leg): n_steps eager SGLD steps, same arguments and effect as
  * pyz_sgld_run, with HIP events recorded on `stream` around the kernels of every step.
  * h_avg_us[3] = average in-pipeline duration in microseconds (launch gap included) of

@@ -288,3 +288,24 @@ def test_sgd_quiet_train_is_the_step_loop():
     assert not torch.equal(a._mean_dev, a._theta)            # 75 steps: the last "mean <- weights" was at count 72
     np.testing.assert_allclose(float(a._running_dev), float(b._running_dev), rtol=1e-5)
     assert a.last_losses.shape == (n_it,) and abs(float(a._loss_dev) - float(b._loss_dev)) < 1e-6
+
+
+def test_swag_quiet_train_is_the_step_loop():
+    """verbose=False runs the SWAG train loop on the device (pyz_swag_run): same weights, moments and
+    deviation rows as the per-step loop, including the column that is replaced once k exist."""
+    def make():
+        ds = moons_dataset(seed=6)
+        start = model_from_json(MOONS_JSON)
+        start.reset_glorot(np.random.default_rng(10))
+        opt = SWAG()
+        opt.compile(HyperParameters(lr=0.03, k=4, frequency=5, scale=1.0, batch_size=64), MOONS_JSON, ds, verbose=False,
+                    starting_model=start, seed=12)
+        return opt
+    a, b = make(), make()
+    a.train(40)
+    a.train(37)                                              # a second run continues the count (77 steps: 16 hits)
+    for _ in range(77):
+        b.step()
+    assert a._n == b._n == 77 and a._n_cols == b._n_cols == 4
+    for name in ("_theta", "_mean_dev", "_sq_mean_dev", "_dev_rows"):
+        np.testing.assert_allclose(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), rtol=0, atol=1e-6, err_msg=name)
