@@ -2,6 +2,8 @@
 
 from __future__ import annotations
 
+import fcntl
+import glob
 import os
 import shutil
 import subprocess
@@ -9,35 +11,48 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpyz.so")
 SOURCES = ["pyz_api.hip"]
-HEADERS = ["pyz_common.h", "pyz_gemm.h", "pyz_kernels.h", "pyz_rng.h", "pyz_hmc_fused.h",
-           os.path.join("..", "..", "include", "pyz.h")]
+
+
+def _inputs():
+    """Everything the library is compiled from: the translation unit, every header beside it, the C-ABI header."""
+    return ([os.path.join(CSRC, f) for f in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) +
+            [os.path.join(CSRC, "..", "..", "include", "pyz.h")])
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in _inputs())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the library if it is missing or older than its sources; returns its path."""
+    """Compile the library if it is missing or older than its sources; returns its path.
+    Safe when several ranks of one node call it at once: one of them compiles (under a file lock, into a
+    temporary file that is renamed into place), the others wait and find the fresh library."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the gfx950 library")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Wno-pass-failed"] + SOURCES + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():        # another process built it while this one waited
+                return LIB
+            tmp = LIB + f".tmp{os.getpid()}"
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall",
+                   "-Wno-unused-function", "-Wno-pass-failed"] + SOURCES + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
