@@ -172,7 +172,12 @@ int pyz_bbb_step(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const floa
  * {accepted, loss, U0, K0, U1, K1, log_ratio, 0}.  prior_sigma is the raw rho
  * (negative => NaN potential, every non-burn proposal rejected, HMC.py:149-159).
  * d_prior_mean_vec / d_prior_sigma_vec: optional per-element prior (float32[D], shared by the
- * chains) for list-valued priors; NULL = the scalars. */
+ * chains) for list-valued priors; NULL = the scalars.
+ * Small 2-layer models (inputs, classes <= 8, hidden + classes <= 64) run with the chain state in LDS:
+ * one workgroup per chain for many chains, or -- for at most 16 chains and >= 192 rows -- row slices
+ * spread over up to 32 workgroups per chain with one launch per gradient evaluation, replayed as a
+ * hipGraph when `stream` is not the default stream.  Results do not depend on the path beyond float32
+ * summation order. */
 int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const void *d_y,
                  int n_rows, int L, float epsilon, float m, float prior_mean, float prior_sigma,
                  const float *d_prior_mean_vec, const float *d_prior_sigma_vec,
@@ -186,7 +191,9 @@ int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const
  * the Keras-legacy-Adam slots (P_local, D); t is the 1-based Adam step.  The
  * RBF kernel and the repulsion sum are accumulated in float64.  gamma > 0 is
  * the fixed bandwidth (reference: 1.0).  d_loss[0] = sum_i loss_i / M over the
- * local rows. */
+ * local rows.  Under PYZ_SWEEP_JACOBI with M <= 64 and local rows in multiples of four (row0 too) the
+ * sweep reads the particle matrix once per pass for all rows; a shard then gets bit-identical rows to the
+ * whole-matrix call. */
 int pyz_svgd_step(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total,
                   int row0, float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y,
                   const int32_t *d_row_idx, int batch, float lr, float gamma, int64_t t, int sweep,
