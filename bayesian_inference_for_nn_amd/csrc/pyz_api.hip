@@ -1217,6 +1217,17 @@ int pyz_predict(pyz_mlp *m, const float *d_weights, int n_samples, const float *
 }
 
 // ---------------------------------------------------------------- noise
+int pyz_sample_normal_rows(float *d_out, int64_t n_rows, int64_t row_stride, int64_t col0, int64_t len, const float *d_loc,
+                           const float *d_scale, uint64_t seed, uint32_t stream_id, uint32_t first_draw, void *stream) {
+  if (!d_out || !d_loc || !d_scale) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n_rows <= 0 || n_rows > 65535 || len <= 0 || col0 < 0 || col0 + len > row_stride)
+    return pyz_fail(PYZ_E_INVALID, "bad draw count / column range");
+  hipLaunchKernelGGL(k_sample_normal_rows, dim3(cdiv(cdiv(len, 4), 256), (unsigned)n_rows), dim3(256), 0, as_stream(stream), d_out,
+                     (long long)row_stride, (long long)col0, (long long)len, d_loc, d_scale, seed, stream_id, first_draw);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
 int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step, float mean, float std,
                     void *stream) {
   if (!d_out || n <= 0) return pyz_fail(PYZ_E_INVALID, "bad output buffer");

@@ -846,6 +846,23 @@ __global__ void k_predict_finish(const float *last, long long pstride, int C, in
   }
 }
 
+// n_rows independent draws of a vector Normal(loc, scale) written into columns [col0, col0 + len) of a
+// row-major (n_rows, row_stride) matrix: out[r][col0 + e] = loc[e] + scale[e] z, z from Philox (seed, stream,
+// step = first_draw + r, e / 4).  (BayesianModel._sample_weights, BayesianModel.py:63-77, for Normal posteriors.)
+__global__ void k_sample_normal_rows(float *out, long long row_stride, long long col0, long long len, const float *loc,
+                                     const float *scale, uint64_t seed, uint32_t stream, uint32_t first_draw) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 4 * t;
+  if (e0 >= len) return;
+  const int r = blockIdx.y;
+  const float4 q = pyz_normal4(seed, stream, first_draw + (uint32_t)r, (uint64_t)t);
+  const float z[4] = {q.x, q.y, q.z, q.w};
+  float *o = out + (long long)r * row_stride + col0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e0 + j < len) o[e0 + j] = loc[e0 + j] + scale[e0 + j] * z[j];
+}
+
 // model output for pyz_mlp_forward: softmax (if any) applied, no NaN scrubbing
 __global__ void k_forward_finish(const float *last, long long pstride, int C, int softmax, int n, float *out) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;

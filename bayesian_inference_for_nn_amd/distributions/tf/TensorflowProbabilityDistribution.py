@@ -29,6 +29,20 @@ class TensorflowProbabilityDistribution(Distribution):
             return np.repeat(d.loc[None, :], n, axis=0)
         return np.stack([self.sample() for _ in range(n)])
 
+    def sample_n_device(self, n: int, out, col0: int) -> bool:
+        """Device-side draws for Normal / Deterministic posteriors (True when done); other distributions
+        are drawn on the host by the caller."""
+        import torch
+        d = self._tf_distribution
+        if isinstance(d, tfd.Normal) and d.loc.ndim == 1:
+            tfd.take_device_draws(n)                  # the reference draws twice and keeps the second (:55-58)
+            d.sample_n_device(n, out, col0)
+            return True
+        if isinstance(d, tfd.Deterministic) and d.loc.ndim == 1:
+            out[:, col0:col0 + d.loc.shape[0]] = torch.as_tensor(d.loc).to(out.device)
+            return True
+        return False
+
     def store(self, path: str):
         d = self._tf_distribution
         data = {"type": type(d).__name__, "loc": np.asarray(d.loc).tolist()}

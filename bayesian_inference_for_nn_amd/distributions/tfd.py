@@ -10,12 +10,26 @@ import math
 import numpy as np
 
 _rng = np.random.default_rng()
+# device draws (BayesianModel.predict): Philox seed and the next unused draw counter
+_dev_seed = int(np.random.default_rng().integers(1, 2 ** 62))
+_dev_draw = 0
 
 
 def seed(s):
-    """Seeds the host generator used by ``sample()`` (the reference never seeds TF)."""
-    global _rng
+    """Seeds the host generator used by ``sample()`` and the device draws of ``predict`` (the reference
+    never seeds TF)."""
+    global _rng, _dev_seed, _dev_draw
     _rng = np.random.default_rng(s)
+    _dev_seed = int(np.random.default_rng(s).integers(1, 2 ** 62))
+    _dev_draw = 0
+
+
+def take_device_draws(n: int) -> int:
+    """Reserves n draw counters of the device stream; returns the first."""
+    global _dev_draw
+    first = _dev_draw
+    _dev_draw += int(n)
+    return first
 
 
 class Normal:
@@ -33,6 +47,14 @@ class Normal:
 
     def sample(self):
         return (self.loc + self.scale * _rng.standard_normal(self.loc.shape, dtype=np.float32)).astype(np.float32)
+
+    def sample_n_device(self, n: int, out, col0: int):
+        """n draws into columns [col0, col0 + size) of the CUDA matrix `out`, generated on the device."""
+        import torch
+        from .. import engine
+        if getattr(self, "_dev", None) is None:
+            self._dev = (torch.as_tensor(self.loc).cuda(), torch.as_tensor(self.scale).cuda())
+        engine.sample_normal_rows(out, col0, self._dev[0], self._dev[1], _dev_seed, take_device_draws(n))
 
     def log_prob(self, x):
         x = np.asarray(x, dtype=np.float32)

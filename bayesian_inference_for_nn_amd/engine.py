@@ -315,3 +315,14 @@ def fill_normal(out: torch.Tensor, seed: int, stream_id: int, step: int, mean: f
     check(lib.pyz_fill_normal(ptr(out), out.numel(), int(seed), int(stream_id), int(step), float(mean), float(std),
                               _stream()))
     return out
+
+
+def sample_normal_rows(out: torch.Tensor, col0: int, loc: torch.Tensor, scale: torch.Tensor, seed: int, first_draw: int):
+    """out[r, col0:col0+len] = loc + scale * z_r for every row r of the (n, stride) CUDA matrix `out`."""
+    lib = _lib.load()
+    _f32(out, name="out")
+    _f32(loc, name="loc")
+    _f32(scale, (loc.numel(),), "scale")
+    assert out.dim() == 2
+    check(lib.pyz_sample_normal_rows(ptr(out), out.shape[0], out.shape[1], int(col0), loc.numel(), ptr(loc), ptr(scale),
+                                     int(seed), _lib.STREAM_PREDICT, int(first_draw) & 0xFFFFFFFF, _stream()))

@@ -210,6 +210,14 @@ int pyz_predict(pyz_mlp *mlp, const float *d_weights, int n_samples, const float
 int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step,
                     float mean, float std, void *stream);
 
+/* n_rows draws of a vector Normal(d_loc, d_scale) (float32[len]) into columns [col0, col0 + len) of the
+ * row-major (n_rows, row_stride) matrix d_out: the weight draws of BayesianModel._sample_weights
+ * (BayesianModel.py:63-77) for Normal posteriors, made where pyz_predict reads them.  Draw r uses the
+ * Philox counter (seed, stream_id, first_draw + r). */
+int pyz_sample_normal_rows(float *d_out, int64_t n_rows, int64_t row_stride, int64_t col0, int64_t len,
+                           const float *d_loc, const float *d_scale, uint64_t seed,
+                           uint32_t stream_id, uint32_t first_draw, void *stream);
+
 /* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE kernel of the
  * gradient step on the workspace left by the last pyz_mlp_loss_grad call with the same
  * arguments.  kind: 0 = k_dense_fwd of `layer` (G1), 1 = k_dense_bwd_data of `layer`,

@@ -309,3 +309,35 @@ def test_swag_quiet_train_is_the_step_loop():
     assert a._n == b._n == 77 and a._n_cols == b._n_cols == 4
     for name in ("_theta", "_mean_dev", "_sq_mean_dev", "_dev_rows"):
         np.testing.assert_allclose(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), rtol=0, atol=1e-6, err_msg=name)
+
+
+def test_predict_draws_normal_posteriors_on_the_device():
+    """BayesianModel.predict with Normal posteriors: the weight draws come from the device Philox stream --
+    right moments, reproducible under tfd.seed, different from draw to draw; a Deterministic layer is copied."""
+    from bayesian_inference_for_nn_amd.distributions import tfd
+    from bayesian_inference_for_nn_amd.distributions.tf import TensorflowProbabilityDistribution
+    cfg = sequential_json(6, [40, 3], ["relu", "softmax"])
+    bm = BayesianModel(cfg)
+    rng = np.random.default_rng(1)
+    sl0, sl1 = bm._model.spec.layer_slices()
+    loc0 = (rng.normal(size=sl0.stop - sl0.start) * 0.3).astype(np.float32)
+    sc0 = np.full_like(loc0, 0.05)
+    det = (rng.normal(size=sl1.stop - sl1.start) * 0.3).astype(np.float32)
+    bm.apply_distribution(TensorflowProbabilityDistribution(tfd.Normal(loc0, sc0)), 0, 0)
+    bm.apply_distribution(TensorflowProbabilityDistribution(tfd.Deterministic(det)), 1, 1)
+    tfd.seed(7)
+    W = bm.sample_weights_device(4000).cpu().numpy()
+    np.testing.assert_array_equal(W[:, sl1], np.repeat(det[None, :], 4000, axis=0))
+    np.testing.assert_allclose(W[:, sl0].mean(0), loc0, atol=0.005)
+    np.testing.assert_allclose(W[:, sl0].std(0), sc0, rtol=0.08)
+    assert not np.array_equal(W[0, sl0], W[1, sl0])
+    tfd.seed(7)
+    np.testing.assert_array_equal(bm.sample_weights_device(4000).cpu().numpy(), W)
+    x = rng.normal(size=(50, 6)).astype(np.float32)
+    tfd.seed(7)
+    W16 = bm.sample_weights_device(16).cpu().numpy()
+    tfd.seed(7)
+    samples, mean = bm.predict(x, nb_samples=16)          # the same 16 draws
+    rs, rm = o_predict.predict(W16, x, o_mlp.MLPSpec((6, 40, 3), ("relu", "softmax"), "scce"))
+    np.testing.assert_allclose(np.stack(samples), rs, atol=1e-5)
+    np.testing.assert_allclose(mean, rm, atol=1e-5)
