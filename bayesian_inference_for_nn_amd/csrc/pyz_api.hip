@@ -40,6 +40,13 @@ struct Extra {  // lazily sized buffers kept beside the plan
   size_t tab_cap_bytes = 0;
   void *tab_host = nullptr;  // pinned
   size_t tab_host_cap = 0;
+  // per-proposal HMC scalars (uniforms + HmcCall) go up through a ring of pinned slots: a copy from pageable
+  // memory would make every pyz_hmc_step wait for the stream, i.e. serialise the host with the device
+  static constexpr int UP_SLOTS = 64;
+  unsigned char *up_host = nullptr;
+  size_t up_slot_bytes = 0;
+  hipEvent_t up_ev[UP_SLOTS] = {};
+  unsigned long long up_count = 0;
 };
 
 }  // namespace
@@ -484,6 +491,10 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) (void)hipHostFree(m->x.tab_host);
+  if (m->x.up_host) {
+    (void)hipHostFree(m->x.up_host);
+    for (auto &e : m->x.up_ev) (void)hipEventDestroy(e);
+  }
   if (m->h_pinned) (void)hipHostFree(m->h_pinned);
   delete m;
   return PYZ_OK;
@@ -910,11 +921,22 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   float *unif = m->scal + 9 * m->max_p;  // [max_p] uniforms, then one HmcCall
   HmcCall *call_dev = reinterpret_cast<HmcCall *>(m->scal + 10 * m->max_p);  // float index 10 max_p is even
   {
-    std::vector<unsigned char> up(sizeof(float) * (size_t)m->max_p + sizeof(HmcCall));
-    memcpy(up.data(), h_uniform, sizeof(float) * P);
+    const size_t up_bytes = sizeof(float) * (size_t)m->max_p + sizeof(HmcCall);
+    Extra &x = f->x;
+    if (!x.up_host) {
+      x.up_slot_bytes = (up_bytes + 63) / 64 * 64;
+      PYZ_HIP(hipHostMalloc((void **)&x.up_host, x.up_slot_bytes * Extra::UP_SLOTS));
+      for (auto &e : x.up_ev) PYZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const unsigned slot = (unsigned)(x.up_count % Extra::UP_SLOTS);
+    if (x.up_count >= (unsigned long long)Extra::UP_SLOTS) PYZ_HIP(hipEventSynchronize(x.up_ev[slot]));  // its last copy has left
+    ++x.up_count;
+    unsigned char *up = x.up_host + x.up_slot_bytes * slot;
+    memcpy(up, h_uniform, sizeof(float) * P);
     HmcCall hc{seed, (uint32_t)step, burning ? 1 : 0};
-    memcpy(up.data() + sizeof(float) * (size_t)m->max_p, &hc, sizeof hc);
-    PYZ_HIP(hipMemcpyAsync(unif, up.data(), up.size(), hipMemcpyHostToDevice, st));
+    memcpy(up + sizeof(float) * (size_t)m->max_p, &hc, sizeof hc);
+    PYZ_HIP(hipMemcpyAsync(unif, up, up_bytes, hipMemcpyHostToDevice, st));
+    PYZ_HIP(hipEventRecord(x.up_ev[slot], st));
   }
   {
     // small 2-layer models: the whole proposal in one workgroup per chain (pyz_hmc_fused.h)

@@ -175,47 +175,99 @@ class Optimizer(ABC):
         """shuffle(cardinality).batch(batch_size) + iter (Optimizer.py:35-41): a device permutation
         per epoch, ragged last batch, fresh permutation when exhausted."""
         self._training_dataset = self._dataset.training_dataset()
+        self._perm_host = None
         self._perm_dev = None
         self._pos = 0
         self._epoch = -1
 
     def _new_epoch(self):
-        import torch
         self._epoch += 1
-        perm = self._rng.permutation(self._training_dataset_cardinality).astype(np.int32)
-        self._perm_dev = torch.as_tensor(perm).cuda()
+        self._perm_host = self._rng.permutation(self._training_dataset_cardinality).astype(np.int32)
+        self._perm_dev = None                        # uploaded when a step() asks for a batch of it
         self._pos = 0
 
     def _next_batch(self):
         """(row-index view on the device, batch size, True when a new epoch started)."""
+        import torch
         new_epoch = False
-        if self._perm_dev is None or self._pos >= self._training_dataset_cardinality:
-            new_epoch = self._perm_dev is not None
+        if self._perm_host is None or self._pos >= self._training_dataset_cardinality:
+            new_epoch = self._perm_host is not None
             self._new_epoch()
+        if self._perm_dev is None:
+            self._perm_dev = torch.as_tensor(self._perm_host).cuda()
         b = min(int(self._batch_size), self._training_dataset_cardinality - self._pos)
         idx = self._perm_dev[self._pos:self._pos + b]
         self._pos += b
         return idx, b, new_epoch
 
     def _batch_plan(self, n_steps: int):
-        """Row indices of the next n_steps batches as one (n_steps, max_batch) table + sizes."""
+        """Row indices of the next n_steps batches as one host (n_steps, max_batch) table + sizes (whole epochs
+        are laid out with one reshape each: no per-step host work)."""
         import torch
         B = self._plan.max_batch
+        N = self._training_dataset_cardinality
+        bsz = int(self._batch_size)
         table = np.zeros((n_steps, B), dtype=np.int32)
         sizes = []
         self._plan_epoch_starts = []                 # steps of this plan that opened a new epoch
-        host_perm = None if self._perm_dev is None else self._perm_dev.cpu().numpy()
-        for s in range(n_steps):
-            if host_perm is None or self._pos >= self._training_dataset_cardinality:
-                if host_perm is not None:
+        s = 0
+        while s < n_steps:
+            if self._perm_host is None or self._pos >= N:
+                if self._perm_host is not None:
                     self._plan_epoch_starts.append(s)
                 self._new_epoch()
-                host_perm = self._perm_dev.cpu().numpy()
-            b = min(int(self._batch_size), self._training_dataset_cardinality - self._pos)
-            table[s, :b] = host_perm[self._pos:self._pos + b]
-            self._pos += b
-            sizes.append(b)
-        return torch.as_tensor(table).cuda(), sizes
+            rest = self._perm_host[self._pos:]
+            nb = min(-(-len(rest) // bsz), n_steps - s)          # batches taken from this epoch
+            take = min(len(rest), nb * bsz)
+            full, tail = divmod(take, bsz)
+            if full:
+                table[s:s + full, :bsz] = rest[:full * bsz].reshape(full, bsz)
+            if tail:
+                table[s + full, :tail] = rest[full * bsz:take]
+            sizes += [bsz] * full + ([tail] if tail else [])
+            self._pos += take
+            s += nb
+        return torch.as_tensor(table), sizes
+
+    def _reserve_resident(self, n_steps: int):
+        """Persistent device buffers for the device-resident runs: the row-index table and the per-step losses.
+        Their addresses are baked into the library's captured hipGraph, so they are kept (and only grown)
+        across train() calls -- fresh tensors per call would re-capture and re-instantiate the graph each time."""
+        import torch
+        if n_steps > getattr(self, "_res_cap", 0):
+            cap = max(256, 1 << (n_steps - 1).bit_length())
+            self._res_idx = torch.zeros((cap, self._plan.max_batch), dtype=torch.int32, device="cuda")
+            self._res_losses = torch.zeros(cap, device="cuda")
+            self._res_cap = cap
+
+    def _resident_buffers(self, table, n_steps: int):
+        """(row-index table, loss buffer) on the device with `table` in the first n_steps slots."""
+        self._reserve_resident(n_steps)
+        self._res_idx[:n_steps].copy_(table)
+        return self._res_idx, self._res_losses
+
+    _resident_chunks = (128, 512)                    # steps in the first / in every later chunk of a resident run
+
+    def _run_resident_chunks(self, nb_iterations: int, launch):
+        """A device-resident run, planned and launched in chunks: the host lays out the batches of the next chunk
+        (one permutation per epoch) while the device works through the current one.
+        launch(row_idx, losses, batch_sizes, s0) enqueues steps [s0, s0 + len(batch_sizes)) on the current stream;
+        returns the losses of the run (a view of the persistent buffer)."""
+        import torch
+        first, chunk = self._resident_chunks
+        self._reserve_resident(nb_iterations)
+        main, stream = torch.cuda.current_stream(), torch.cuda.Stream()      # (graph replay needs its own stream)
+        s0 = 0
+        while s0 < nb_iterations:
+            n = min(first if s0 == 0 else chunk, nb_iterations - s0)
+            table, sizes = self._batch_plan(n)
+            self._res_idx[s0:s0 + n].copy_(table)
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                launch(self._res_idx, self._res_losses, sizes, s0)
+            s0 += n
+        main.wait_stream(stream)
+        return self._res_losses[:nb_iterations]
 
     def _layer_indices(self):
         """indices (in model.layers) of the layers that own parameters"""

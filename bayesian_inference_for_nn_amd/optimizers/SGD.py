@@ -63,9 +63,10 @@ class SGD(Optimizer):
         from .._lib import PyzError
         if nb_iterations <= 0:
             return True
-        idx, sizes = self._batch_plan(nb_iterations)
+        table, sizes = self._batch_plan(nb_iterations)
+        idx, loss_buf = self._resident_buffers(table, nb_iterations)
+        losses = loss_buf[:nb_iterations]
         lrs = [float(self._lr)] * nb_iterations
-        losses = torch.zeros(nb_iterations, device="cuda")
         freq = int(self._frequency)
         hits = [s for s in range(nb_iterations) if (self._n + s) % freq == 0]
         cut = hits[-1] + 1 if hits else 0             # steps [0, cut) end with the last "mean <- weights"
@@ -94,7 +95,7 @@ class SGD(Optimizer):
             self._running_dev.copy_(losses[last_epoch:].sum().reshape(1))
         self._loss_dev.copy_(losses[-1:])
         self._n += nb_iterations
-        self.last_losses = losses
+        self.last_losses = losses.clone()          # the buffer itself is reused by the next run
         return True
 
     def result(self) -> BayesianModel:

@@ -69,18 +69,15 @@ class SGLD(Optimizer):
     def _train_resident(self, nb_iterations: int) -> bool:
         """verbose=False: all steps in one device-resident run (hipGraph replay, no host sync)."""
         import torch
-        idx, sizes = self._batch_plan(nb_iterations)
-        lrs = [float(np.float32(self._lr(self._n + s))) for s in range(nb_iterations)]
-        losses = torch.zeros(nb_iterations, device="cuda")
-        stream = torch.cuda.Stream()
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
+        lrs = np.asarray(self._lr(self._n + np.arange(nb_iterations, dtype=np.float64))).astype(np.float32).tolist()
+
+        def launch(idx, loss_buf, sizes, s0):
             self._plan.sgld_run(self._theta, self._mean_dev, self._sq_mean_dev, self._x_dev, self._y_dev, idx, sizes,
-                                lrs, self._n, self._seed, losses, use_graph=True)
-        torch.cuda.current_stream().wait_stream(stream)
+                                lrs[s0:s0 + len(sizes)], self._n + s0, self._seed, loss_buf, use_graph=True, slot0=s0)
+        losses = self._run_resident_chunks(nb_iterations, launch)
         self._running_dev += losses.sum()
         self._n += nb_iterations
-        self.last_losses = losses
+        self.last_losses = losses.clone()          # the buffer itself is reused by the next run
         return True
 
     def update_parameters_step(self):

@@ -63,21 +63,18 @@ class SWAG(Optimizer):
         from .._lib import PyzError
         if nb_iterations <= 0:
             return True
-        idx, sizes = self._batch_plan(nb_iterations)
-        losses = torch.zeros(nb_iterations, device="cuda")
-        stream = torch.cuda.Stream()
-        stream.wait_stream(torch.cuda.current_stream())
+        def launch(idx, loss_buf, sizes, s0):
+            self._plan.swag_run(self._theta, self._mean_dev, self._sq_mean_dev, self._dev_rows, self._frequency,
+                                self._x_dev, self._y_dev, idx, sizes, [float(self._lr)] * len(sizes), self._n + s0,
+                                loss_buf, slot0=s0)
         try:
-            with torch.cuda.stream(stream):
-                self._plan.swag_run(self._theta, self._mean_dev, self._sq_mean_dev, self._dev_rows, self._frequency,
-                                    self._x_dev, self._y_dev, idx, sizes, [float(self._lr)] * nb_iterations, self._n, losses)
+            losses = self._run_resident_chunks(nb_iterations, launch)
         except PyzError:                              # shapes the fused step does not take: per-step loop
             return False
-        torch.cuda.current_stream().wait_stream(stream)
         self._n += nb_iterations
         self._n_cols = min(self._k, -(-self._n // self._frequency))      # hits among counts 0 .. n - 1
         self._loss_dev.copy_(losses[-1:])
-        self.last_losses = losses
+        self.last_losses = losses.clone()          # the buffer itself is reused by the next run
         return True
 
     def update_parameters_step(self):

@@ -92,6 +92,7 @@ def test_sgld_surface_matches_oracle_and_resident_training():
     a, b2 = SGLD(), SGLD()
     a.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
     b2.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
+    a._resident_chunks = (40, 20)                            # planned and launched as 40 + 20 + 10 steps
     a.train(70)
     b2._nb_iterations = 70
     b2._init_sgld_lr()
@@ -290,6 +291,32 @@ def test_sgd_quiet_train_is_the_step_loop():
     assert a.last_losses.shape == (n_it,) and abs(float(a._loss_dev) - float(b._loss_dev)) < 1e-6
 
 
+def test_quiet_train_calls_share_their_device_buffers():
+    """Successive verbose=False runs reuse one row-index table and one loss buffer (so the captured graph
+    is replayed, not rebuilt); a longer run grows them.  Results equal the per-step loop throughout."""
+    def make():
+        ds = moons_dataset(seed=7)
+        start = model_from_json(MOONS_JSON)
+        start.reset_glorot(np.random.default_rng(13))
+        opt = SGD()
+        opt.compile(HyperParameters(lr=0.05, frequency=3, batch_size=64), MOONS_JSON, ds, verbose=False, starting_model=start, seed=14)
+        return opt
+    a, b = make(), make()
+    a.train(20)
+    first = a.last_losses.cpu().numpy().copy()
+    buf = a._res_idx.data_ptr()
+    a.train(33)
+    assert a._res_idx.data_ptr() == buf and a._res_cap == 256
+    assert first.shape == (20,) and a.last_losses.shape == (33,)
+    a.train(280)                                             # beyond the first capacity: new buffers, new graph
+    assert a._res_cap == 512 and a._res_idx.data_ptr() != buf
+    for _ in range(333):
+        b.step()
+    assert a._n == b._n == 333 and a._epoch_num == b._epoch_num
+    np.testing.assert_allclose(a._theta.cpu().numpy(), b._theta.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a._mean_dev.cpu().numpy(), b._mean_dev.cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_swag_quiet_train_is_the_step_loop():
     """verbose=False runs the SWAG train loop on the device (pyz_swag_run): same weights, moments and
     deviation rows as the per-step loop, including the column that is replaced once k exist."""
@@ -302,6 +329,7 @@ def test_swag_quiet_train_is_the_step_loop():
                     starting_model=start, seed=12)
         return opt
     a, b = make(), make()
+    a._resident_chunks = (16, 12)                            # several plan/launch chunks per run
     a.train(40)
     a.train(37)                                              # a second run continues the count (77 steps: 16 hits)
     for _ in range(77):
