@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "bayesian_inference_for_nn_amd", "csrc")
 lib = os.path.join(csrc, "libpyz_stamps.so")
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPYZ_STAMPS",
-                       "-Wno-unused-function", "-Wno-pass-failed"] + os.environ.get("PYZ_STAMP_FLAGS", "").split() +
-                      ["pyz_api.hip", "-o", lib], cwd=csrc)
+if os.environ.get("PYZ_STAMPS_LIB"):          # a prebuilt -DPYZ_STAMPS library (A/B of two source states on one box)
+    lib = os.environ["PYZ_STAMPS_LIB"]
+else:
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DPYZ_STAMPS",
+                           "-Wno-unused-function", "-Wno-pass-failed"] + os.environ.get("PYZ_STAMP_FLAGS", "").split() +
+                          ["pyz_api.hip", "-o", lib], cwd=csrc)
 from bayesian_inference_for_nn_amd import _build
 _build.LIB = lib
 _build.build = lambda *a, **k: lib
