@@ -1203,10 +1203,41 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
   } else {
-    for (int i = 0; i < n_local; ++i) {
-      a.i_local = i;
-      hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, 1), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
+    const int gs_fused = pyz_env_int("PYZ_SVGD_GS_FUSED", 1);  // read per call: tests flip it
+    const long long gs_range = 256LL * PYZ_GS_E;
+    if (gs_fused && n_total <= 64 && m->D <= 256 * gs_range) {
+      // one launch per particle, the matrix read once per launch (k_svgd_gs)
+      SvgdGsArgs ga{};
+      ga.all = d_particles;
+      ga.adam_m = d_adam_m;
+      ga.adam_v = d_adam_v;
+      ga.grad = m->grad;
+      ga.D = m->D;
+      ga.M = n_total;
+      ga.lr_t = a.lr_t;
+      ga.gamma = gamma;
+      ga.nblk = (int)cdiv(m->D, gs_range);
+      const size_t n_part = (size_t)ga.nblk * 64;
+      if ((rc = need_part2(m, 2 * n_part + 8))) return rc;
+      double *pp[2] = {full(m)->x.part2, full(m)->x.part2 + n_part};
+      const size_t gs_lds = pyz_svgd_gs_lds_bytes();
+      static bool gs_attr = false;
+      if (!gs_attr) {
+        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
+        gs_attr = true;
+      }
+      for (int i = -1; i < n_total; ++i) {
+        ga.i = i;
+        ga.part_in = pp[(i + 2) & 1];   // what launch i - 1 wrote
+        ga.part_out = pp[(i + 1) & 1];
+        hipLaunchKernelGGL(k_svgd_gs, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
+      }
+    } else {
+      for (int i = 0; i < n_local; ++i) {
+        a.i_local = i;
+        hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, 1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
+      }
     }
   }
   hipLaunchKernelGGL(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);

@@ -808,6 +808,165 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
   }
 }
 
+// ---------------------------------------------------------------- Gauss-Seidel sweep, one launch per particle
+// The reference updates the particles one after the other, each against the rows already updated
+// (SVGD.py:110-120).  With the per-row kernels above that is two launches per particle, each reading the whole
+// (M, D) matrix: 2 x 40.7 MB at C5.  k_svgd_gs does one particle per launch and reads the matrix once:
+//   a workgroup owns 256 * PYZ_GS_E consecutive elements of D and keeps x_j[d] of ALL particles in registers;
+//   launch i  (a) sums the squared-distance partials of row i that launch i - 1 left (float64, block order),
+//                 K_ij = exp(-gamma d_ij), sum_j K_ij;
+//             (b) phi_i and the Adam step on its elements (the formulas and the order over j of k_svgd_update),
+//                 stores x_i and patches its register copy;
+//             (c) leaves the partials of row i + 1 against the matrix as it now stands.
+//   The launch with i = -1 only does (c) for row 0.  Partials ping-pong between two buffers (a workgroup writes
+//   its new partials while others still read the old ones).  Needs M <= 64 and D <= 256 * 256 * PYZ_GS_E
+//   (every workgroup reads all partials: one round of workgroups); else the per-row kernels run.
+#define PYZ_GS_E 3
+#define PYZ_GS_PAD 257   // row stride (doubles) of the reduction scratch: conflict-free column sums
+typedef float pyz_gs_vec __attribute__((ext_vector_type(PYZ_GS_E), aligned(4)));  // a thread's elements of one row
+
+struct SvgdGsArgs {
+  float *all;              // (M, D) particle matrix, updated in place
+  float *adam_m, *adam_v;  // (M, D)
+  const float *grad;       // (M, D)
+  long long D;
+  int M;
+  int i;                   // particle of this launch; -1: only the distances of row 0
+  float lr_t, gamma;
+  const double *part_in;   // (nblk, 64) partials of row i
+  double *part_out;        // (nblk, 64) partials of row i + 1
+  int nblk;
+};
+
+static inline size_t pyz_svgd_gs_lds_bytes() { return sizeof(double) * (64 * PYZ_GS_PAD + 5 * 64); }
+
+// LDS-only workgroup barrier: __syncthreads() also waits for the global loads in flight (one counter for loads
+// and stores on this target), which would serialise the phases below
+__device__ __forceinline__ void pyz_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
+  extern __shared__ double gs_lds[];
+  double *red = gs_lds;                  // [64][PYZ_GS_PAD]
+  double *ps4 = red + 64 * PYZ_GS_PAD;   // [4][64]
+  double *sd = ps4 + 4 * 64;             // [64]
+  const int tid = threadIdx.x, M = g.M, i = g.i;
+  const long long D = g.D, base = (long long)blockIdx.x * (256 * PYZ_GS_E);
+  // -- requests first, in the order they are consumed: the partials of row i (at most 256 blocks: 64 per thread,
+  //    4 threads per row j), then the matrix; the K row is built while the matrix is still on its way
+  const int pj = tid & 63, pq = tid >> 6;
+  double pv[64];
+  if (i >= 0) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) pv[u] = g.part_in[(long long)min(pq + 4 * u, g.nblk - 1) * 64 + pj];
+  }
+  // a thread owns PYZ_GS_E CONSECUTIVE elements: one 12-byte load per particle row
+  long long e[PYZ_GS_E];
+  bool in[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) {
+    e[q] = base + PYZ_GS_E * tid + q;
+    in[q] = e[q] < D;
+    e[q] = in[q] ? e[q] : D - 1;
+  }
+  const bool whole = in[PYZ_GS_E - 1];  // all of this thread's elements exist
+  float x[64][PYZ_GS_E];
+  if (whole) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const pyz_gs_vec v = *reinterpret_cast<const pyz_gs_vec *>(g.all + (long long)min(j, M - 1) * D + e[0]);
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = v[q];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const float *row = g.all + (long long)min(j, M - 1) * D;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = row[e[q]];
+    }
+  }
+  const int inext = i + 1;
+  float xnext[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) xnext[q] = inext < M ? g.all[(long long)inext * D + e[q]] : 0.0f;
+  if (i >= 0) {
+    float xi[PYZ_GS_E], gi[PYZ_GS_E], am[PYZ_GS_E], av[PYZ_GS_E];
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      const long long o = (long long)i * D + e[q];
+      xi[q] = g.all[o];
+      gi[q] = g.grad[o];
+      am[q] = g.adam_m[o];
+      av[q] = g.adam_v[o];
+    }
+    {  // squared distances of row i: the partials of row j are summed by 4 threads (stride-4 slices), fixed order
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) s += (pq + 4 * u < g.nblk) ? pv[u] : 0.0;
+      ps4[pq * 64 + pj] = s;
+    }
+    pyz_lds_barrier();
+    if (tid < 64) sd[tid] = tid < M ? exp(-(double)g.gamma * ((ps4[tid] + ps4[64 + tid]) + (ps4[128 + tid] + ps4[192 + tid]))) : 0.0;
+    pyz_lds_barrier();
+    // the K row into registers in one batch of LDS reads (a loop that reads sd[j] and branches on it pays the LDS
+    // latency 64 times); rows past M hold 0, row i and underflowed rows contribute exactly 0 as in k_svgd_update
+    double kr[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) kr[j] = sd[j];
+    float ksum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) ksum += (float)kr[j];   // (+0.0f past M: the sum over j < M, same order)
+    double rep[PYZ_GS_E];
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const double kj = (j == i) ? 0.0 : kr[j];
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) rep[q] += kj * ((double)xi[q] - (double)x[j][q]);
+    }
+    float xn[PYZ_GS_E];
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      const float phi = (ksum * gi[q] + (float)(rep[q] * (2.0 * (double)g.gamma))) / (float)M;
+      const float m = am[q] + (phi - am[q]) * (1.0f - 0.9f);
+      const float v = av[q] + (phi * phi - av[q]) * (1.0f - 0.999f);
+      xn[q] = xi[q] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+      if (in[q]) {
+        const long long o = (long long)i * D + e[q];
+        g.adam_m[o] = m;
+        g.adam_v[o] = v;
+        g.all[o] = xn[q];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j)
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = (j == i) ? xn[q] : x[j][q];
+  }
+  if (inext >= M) return;
+  // partial squared distances of row i + 1 against every row (differences and squares in float64: SVGD.py:198-201)
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      const double df = in[q] ? (double)xnext[q] - (double)x[j][q] : 0.0;
+      acc += df * df;
+    }
+    red[j * PYZ_GS_PAD + tid] = acc;
+  }
+  pyz_lds_barrier();  // (also orders the ps4 reads of the K row before the writes below)
+  {
+    const double *rp = red + pj * PYZ_GS_PAD + 64 * pq;
+    double s = 0.0;
+    for (int t = 0; t < 64; ++t) s += rp[t];
+    ps4[pq * 64 + pj] = s;
+  }
+  pyz_lds_barrier();
+  if (tid < 64) g.part_out[(long long)blockIdx.x * 64 + tid] = tid < M ? (ps4[tid] + ps4[64 + tid]) + (ps4[128 + tid] + ps4[192 + tid]) : 0.0;
+}
+
 // d_loss[0] = sum_i loss_i / M   (SVGD.py:125)
 __global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

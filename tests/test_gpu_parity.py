@@ -428,6 +428,38 @@ def test_svgd_step_matches_oracle(eng, sweep):
     plan.close()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_svgd_gauss_seidel_paths(eng, monkeypatch, fused):
+    """The reference-order sweep as one launch per particle (k_svgd_gs: the matrix in registers, partial
+    distances handed from launch to launch) and as the two per-row kernels: both against the oracle, on a
+    model whose parameters span several workgroups (D = 3 834 > 768, ragged last one) with particles close
+    enough for the kernel matrix to couple them (K_ij ~ 0.05).
+    Adam's first steps move every element by ~lr * sign(phi): where phi is ~0 (dead units) float32 and float64
+    may disagree on the sign, so the update direction is checked through Adam's m and v (linear / quadratic in
+    phi), and the particles on all but a handful of elements."""
+    monkeypatch.setenv("PYZ_SVGD_GS_FUSED", str(fused))
+    spec, n = SPECS["wide3"]
+    x, y, _ = make(spec, n, seed=57)
+    D = spec.n_params
+    M, lr = 7, 1e-3
+    parts = (np.random.default_rng(58).normal(size=(M, D)) * 0.02).astype(np.float32)
+    st = o_svgd.SVGDState(parts)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=M)
+    p = dev(parts)
+    am, av = torch.zeros((M, D), device="cuda"), torch.zeros((M, D), device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    for t in range(1, 3):
+        plan.svgd_step(p, p, 0, am, av, dev(x), ydev(spec, y), lr, 1.0, t, loss, sweep="gauss_seidel")
+        out = o_svgd.svgd_step(st, x, y, spec, lr, 1.0, sweep="gauss_seidel")
+        close(loss, [out["loss"]], what="loss")
+    close(am, st.m, what="adam m", rel=5e-4)
+    close(av, st.v, what="adam v", rel=5e-4)
+    err = np.abs(p.cpu().numpy().astype(np.float64) - st.particles)
+    assert err.max() <= 4.5 * lr, err.max()                   # at worst a sign flip in both steps
+    assert (err > 2e-4 * np.abs(st.particles).max()).mean() < 2e-3
+    plan.close()
+
+
 def test_svgd_jacobi_shard_equals_whole(eng):
     """Rows [2,5) updated as a shard against the gathered matrix == the same rows of a whole-matrix Jacobi step."""
     spec, n = SPECS["tiny_cls"]
