@@ -822,8 +822,10 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
 //   its new partials while others still read the old ones).  Needs M <= 64 and D <= 256 * 256 * PYZ_GS_E
 //   (every workgroup reads all partials: one round of workgroups); else the per-row kernels run.
 #define PYZ_GS_E 3
+#define PYZ_GS_AHEAD 32  // rows requested ahead of the arithmetic
 #define PYZ_GS_PAD 257   // row stride (doubles) of the reduction scratch: conflict-free column sums
 typedef float pyz_gs_vec __attribute__((ext_vector_type(PYZ_GS_E), aligned(4)));  // a thread's elements of one row
+typedef double pyz_gs_d2 __attribute__((ext_vector_type(2)));
 
 struct SvgdGsArgs {
   float *all;              // (M, D) particle matrix, updated in place
@@ -838,26 +840,37 @@ struct SvgdGsArgs {
   int nblk;
 };
 
-static inline size_t pyz_svgd_gs_lds_bytes() { return sizeof(double) * (64 * PYZ_GS_PAD + 5 * 64); }
+static inline size_t pyz_svgd_gs_lds_bytes() { return sizeof(double) * (64 * PYZ_GS_PAD + 9 * 64); }
 
 // LDS-only workgroup barrier: __syncthreads() also waits for the global loads in flight (one counter for loads
 // and stores on this target), which would serialise the phases below
 __device__ __forceinline__ void pyz_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef PYZ_STAMPS
+#define PYZ_GS_STAMP(slot) do { if (g.i == 32) PYZ_STAMP(3, slot); } while (0)   // one mid-sweep launch
+#else
+#define PYZ_GS_STAMP(slot)
+#endif
+
 __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   extern __shared__ double gs_lds[];
+  PYZ_GS_STAMP(0);
   double *red = gs_lds;                  // [64][PYZ_GS_PAD]
-  double *ps4 = red + 64 * PYZ_GS_PAD;   // [4][64]
-  double *sd = ps4 + 4 * 64;             // [64]
+  double *ps8 = red + 64 * PYZ_GS_PAD;   // [8][64] slices of the partial sums
+  double *ps4 = ps8;                     // [4][64] (second use: the block reduction at the end)
+  double *sd = ps8 + 8 * 64;             // [64]
   const int tid = threadIdx.x, M = g.M, i = g.i;
   const long long D = g.D, base = (long long)blockIdx.x * (256 * PYZ_GS_E);
   // -- requests first, in the order they are consumed: the partials of row i (at most 256 blocks: 64 per thread,
   //    4 threads per row j), then the matrix; the K row is built while the matrix is still on its way
   const int pj = tid & 63, pq = tid >> 6;
-  double pv[64];
+  // (partials: a thread takes the row PAIR 2 pj2, 2 pj2 + 1 of every 8th block with 16-byte loads: 32 requests)
+  const int pj2 = tid & 31, pq8 = tid >> 5;
+  pyz_gs_d2 pv[32];
   if (i >= 0) {
 #pragma unroll
-    for (int u = 0; u < 64; ++u) pv[u] = g.part_in[(long long)min(pq + 4 * u, g.nblk - 1) * 64 + pj];
+    for (int u = 0; u < 32; ++u)
+      pv[u] = *reinterpret_cast<const pyz_gs_d2 *>(g.part_in + (long long)min(pq8 + 8 * u, g.nblk - 1) * 64 + 2 * pj2);
   }
   // a thread owns PYZ_GS_E CONSECUTIVE elements: one 12-byte load per particle row
   long long e[PYZ_GS_E];
@@ -868,29 +881,13 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     in[q] = e[q] < D;
     e[q] = in[q] ? e[q] : D - 1;
   }
-  const bool whole = in[PYZ_GS_E - 1];  // all of this thread's elements exist
-  float x[64][PYZ_GS_E];
-  if (whole) {
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const pyz_gs_vec v = *reinterpret_cast<const pyz_gs_vec *>(g.all + (long long)min(j, M - 1) * D + e[0]);
-#pragma unroll
-      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = v[q];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const float *row = g.all + (long long)min(j, M - 1) * D;
-#pragma unroll
-      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = row[e[q]];
-    }
-  }
+  const bool whole = base + (long long)PYZ_GS_E * 64 * (pyz_wave_id() + 1) <= D;  // all elements of this WAVE exist (scalar)
   const int inext = i + 1;
   float xnext[PYZ_GS_E];
 #pragma unroll
   for (int q = 0; q < PYZ_GS_E; ++q) xnext[q] = inext < M ? g.all[(long long)inext * D + e[q]] : 0.0f;
+  float xi[PYZ_GS_E], gi[PYZ_GS_E], am[PYZ_GS_E], av[PYZ_GS_E];
   if (i >= 0) {
-    float xi[PYZ_GS_E], gi[PYZ_GS_E], am[PYZ_GS_E], av[PYZ_GS_E];
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
       const long long o = (long long)i * D + e[q];
@@ -899,63 +896,108 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
       am[q] = g.adam_m[o];
       av[q] = g.adam_v[o];
     }
-    {  // squared distances of row i: the partials of row j are summed by 4 threads (stride-4 slices), fixed order
-      double s = 0.0;
+  }
+  // -- the matrix, PYZ_GS_AHEAD rows ahead of the arithmetic on them: the partial squared distances of row i + 1
+  //    against every row (differences and squares in float64: SVGD.py:198-201) are taken as the rows arrive and
+  //    hide behind the loads.  (Row i is about to change: its term is recomputed below.)  The empty asm pins each
+  //    row's arithmetic between the loads around it: left alone, the compiler sinks it to the LDS writes at the end.
+  float x[64][PYZ_GS_E];
+  double acc[64];
+  auto load_row = [&](const int j) {
+    if (whole) {
+      const pyz_gs_vec v = *reinterpret_cast<const pyz_gs_vec *>(g.all + (long long)min(j, M - 1) * D + e[0]);
 #pragma unroll
-      for (int u = 0; u < 64; ++u) s += (pq + 4 * u < g.nblk) ? pv[u] : 0.0;
-      ps4[pq * 64 + pj] = s;
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = v[q];
+    } else {
+      const float *row = g.all + (long long)min(j, M - 1) * D;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = row[e[q]];
     }
+  };
+#pragma unroll
+  for (int j = 0; j < PYZ_GS_AHEAD; ++j) load_row(j);
+  PYZ_GS_STAMP(1);
+  // -- the K row of particle i, while the first rows are on their way (its partials were requested first)
+  float kf[64];
+  float ksum = 0.0f;
+  if (i >= 0) {
+    {  // squared distances of row i: the partials of a row are summed by 8 threads (stride-8 slices), fixed order
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const bool on = pq8 + 8 * u < g.nblk;
+        s0 += on ? pv[u][0] : 0.0;
+        s1 += on ? pv[u][1] : 0.0;
+      }
+      *reinterpret_cast<pyz_gs_d2 *>(ps8 + pq8 * 64 + 2 * pj2) = pyz_gs_d2{s0, s1};
+    }
+    PYZ_GS_STAMP(2);
     pyz_lds_barrier();
-    if (tid < 64) sd[tid] = tid < M ? exp(-(double)g.gamma * ((ps4[tid] + ps4[64 + tid]) + (ps4[128 + tid] + ps4[192 + tid]))) : 0.0;
+    if (tid < 64) {
+      const double dsq = ((ps8[tid] + ps8[64 + tid]) + (ps8[128 + tid] + ps8[192 + tid])) +
+                         ((ps8[256 + tid] + ps8[320 + tid]) + (ps8[384 + tid] + ps8[448 + tid]));
+      sd[tid] = tid < M ? exp(-(double)g.gamma * dsq) : 0.0;
+    }
     pyz_lds_barrier();
     // the K row into registers in one batch of LDS reads (a loop that reads sd[j] and branches on it pays the LDS
-    // latency 64 times); rows past M hold 0, row i and underflowed rows contribute exactly 0 as in k_svgd_update
-    double kr[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) kr[j] = sd[j];
-    float ksum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) ksum += (float)kr[j];   // (+0.0f past M: the sum over j < M, same order)
-    double rep[PYZ_GS_E];
-#pragma unroll
-    for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
+    // latency 64 times); rows past M hold 0
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-      const double kj = (j == i) ? 0.0 : kr[j];
-#pragma unroll
-      for (int q = 0; q < PYZ_GS_E; ++q) rep[q] += kj * ((double)xi[q] - (double)x[j][q]);
+      kf[j] = (float)sd[j];
+      ksum += kf[j];   // (+0.0f past M: the sum over j < M, same order)
     }
-    float xn[PYZ_GS_E];
+  }
+  PYZ_GS_STAMP(3);
+  float rep[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (j + PYZ_GS_AHEAD < 64) load_row(j + PYZ_GS_AHEAD);
+    double a = 0.0;
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
-      const float phi = (ksum * gi[q] + (float)(rep[q] * (2.0 * (double)g.gamma))) / (float)M;
+      const double df = in[q] ? (double)xnext[q] - (double)x[j][q] : 0.0;
+      a += df * df;
+    }
+    asm volatile("" : "+v"(a)::"memory");
+    acc[j] = a;
+    if (i >= 0) {  // repulsion term of this row, in float32 (see below)
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) {
+        rep[q] = fmaf(kf[j], xi[q] - x[j][q], rep[q]);
+        asm volatile("" : "+v"(rep[q]));
+      }
+    }
+  }
+  PYZ_GS_STAMP(4);
+  double acc_i = 0.0;
+  if (i >= 0) {
+    // (the repulsion sum was taken in float32 as the rows arrived: phi is a float32 quantity and the 64 terms
+    // K_ij (x_i - x_j) carry no cancellation that float32 products would lose against it; row i -- difference
+    // 0 -- and underflowed rows add exactly 0)
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      const float phi = (ksum * gi[q] + rep[q] * (2.0f * g.gamma)) / (float)M;
       const float m = am[q] + (phi - am[q]) * (1.0f - 0.9f);
       const float v = av[q] + (phi * phi - av[q]) * (1.0f - 0.999f);
-      xn[q] = xi[q] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+      const float xn = xi[q] - g.lr_t * m / (sqrtf(v) + 1e-7f);
       if (in[q]) {
         const long long o = (long long)i * D + e[q];
         g.adam_m[o] = m;
         g.adam_v[o] = v;
-        g.all[o] = xn[q];
+        g.all[o] = xn;
+        const double df = (double)xnext[q] - (double)xn;
+        acc_i += df * df;
       }
     }
-#pragma unroll
-    for (int j = 0; j < 64; ++j)
-#pragma unroll
-      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = (j == i) ? xn[q] : x[j][q];
   }
+  PYZ_GS_STAMP(5);
   if (inext >= M) return;
-  // partial squared distances of row i + 1 against every row (differences and squares in float64: SVGD.py:198-201)
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < PYZ_GS_E; ++q) {
-      const double df = in[q] ? (double)xnext[q] - (double)x[j][q] : 0.0;
-      acc += df * df;
-    }
-    red[j * PYZ_GS_PAD + tid] = acc;
-  }
+  for (int j = 0; j < 64; ++j) red[j * PYZ_GS_PAD + tid] = acc[j];
+  if (i >= 0) red[i * PYZ_GS_PAD + tid] = acc_i;   // the updated row i (same thread, after its first write)
+  PYZ_GS_STAMP(6);
   pyz_lds_barrier();  // (also orders the ps4 reads of the K row before the writes below)
   {
     const double *rp = red + pj * PYZ_GS_PAD + 64 * pq;
@@ -965,6 +1007,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   }
   pyz_lds_barrier();
   if (tid < 64) g.part_out[(long long)blockIdx.x * 64 + tid] = tid < M ? (ps4[tid] + ps4[64 + tid]) + (ps4[128 + tid] + ps4[192 + tid]) : 0.0;
+  PYZ_GS_STAMP(7);
 }
 
 // d_loss[0] = sum_i loss_i / M   (SVGD.py:125)
