@@ -189,11 +189,13 @@ int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const
  * (M, D) is the matrix the kernel row is evaluated against (== d_particles on
  * one GPU; the all-gathered snapshot under PYZ_SWEEP_JACOBI).  d_adam_m/v are
  * the Keras-legacy-Adam slots (P_local, D); t is the 1-based Adam step.  The
- * RBF kernel and the repulsion sum are accumulated in float64.  gamma > 0 is
+ * squared distances and the RBF kernel are evaluated in float64.  gamma > 0 is
  * the fixed bandwidth (reference: 1.0).  d_loss[0] = sum_i loss_i / M over the
  * local rows.  Under PYZ_SWEEP_JACOBI with M <= 64 and local rows in multiples of four (row0 too) the
  * sweep reads the particle matrix once per pass for all rows; a shard then gets bit-identical rows to the
- * whole-matrix call. */
+ * whole-matrix call.  Under PYZ_SWEEP_GAUSS_SEIDEL with M <= 64 and D <= 196 608 the sweep is one launch
+ * per particle that reads the matrix once (repulsion sum in float32: phi is a float32 quantity); otherwise
+ * two launches per particle (repulsion sum in float64).  The paths agree within float32 rounding of phi. */
 int pyz_svgd_step(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total,
                   int row0, float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y,
                   const int32_t *d_row_idx, int batch, float lr, float gamma, int64_t t, int sweep,
