@@ -94,14 +94,16 @@ class SVGD(Optimizer):
         if self._world > 1:
             parallel.sum_over_ranks(total_loss)
         loss = DeviceScalar(total_loss, 0)
-        if self._val_n > 0:                                     # SVGD.py:126-129: validation forward per particle
-            vl, _ = self._val_plan.loss_grad(self._local, self._vx, self._vy, want_grad=False)
-            total_val = vl.sum() / self._M
-            if self._world > 1:
-                parallel.sum_over_ranks(total_val)
-        else:
-            total_val = torch.zeros((), device="cuda")
         if self._step % 10 == 0:                                # SVGD.py:137-139
+            # SVGD.py:126-129 forwards the validation split through every particle on every step, but only
+            # these steps keep the number: the forward runs when it is observable
+            if self._val_n > 0:
+                vl, _ = self._val_plan.loss_grad(self._local, self._vx, self._vy, want_grad=False)
+                total_val = vl.sum() / self._M
+                if self._world > 1:
+                    parallel.sum_over_ranks(total_val)
+            else:
+                total_val = torch.zeros((), device="cuda")
             self.train_losses.append(loss)
             self.valid_losses.append(DeviceScalar(total_val.reshape(1), 0))
         return loss
