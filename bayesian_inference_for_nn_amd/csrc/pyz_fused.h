@@ -260,6 +260,14 @@ __device__ __forceinline__ float pyz_row16_allsum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float pyz_row16_allmax(float v) {
+  v = fmaxf(v, pyz_dpp<0xB1>(v));
+  v = fmaxf(v, pyz_dpp<0x4E>(v));
+  v = fmaxf(v, pyz_dpp<0x141>(v));
+  v = fmaxf(v, pyz_dpp<0x140>(v));
+  return v;
+}
+
 template <int UT, int NP>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
@@ -316,50 +324,73 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   }
   PYZ_STAMP(1, 2);
   // ---- loss row and delta_L (every lane holds all N values; padded classes carry zeros)
-  float d2[NP], outv[NP], lm;
-  if (g.loss == PYZ_LOSS_SCCE) {
-    float mx = -3.0e38f;
+  float d2[NP], lm, my_d = 0.0f, my_o = 0.0f;
+  if (g.loss == PYZ_LOSS_SCCE && NP <= 16) {
+    // softmax with the classes spread over the lanes of each 16-lane row (lane c owns class c; the four rows
+    // hold copies): one exp per lane instead of N in sequence on every lane, max and sum by DPP row steps
+    const int lc = l & 15;
+    float zc = z[0];
 #pragma unroll
-    for (int c = 0; c < NP; ++c) mx = fmaxf(mx, c < N ? z[c] : -3.0e38f);
-    float ex[NP], se = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NP; ++c) {
-      ex[c] = c < N ? expf(z[c] - mx) : 0.0f;
-      se += ex[c];
-    }
+    for (int c = 1; c < NP; ++c) zc = (lc == c) ? z[c] : zc;
+    const bool on = lc < N;
+    const float mx = pyz_row16_allmax(on ? zc : -3.0e38f);
+    const float exv = on ? expf(zc - mx) : 0.0f;
+    const float se = pyz_row16_allsum(exv);
     const float lse = mx + logf(se);
-    float zy = __builtin_nanf("");
+    const bool mine = on && lc == ylab;
+    float zy = pyz_row16_allsum(mine ? zc : 0.0f);
+    zy = (ylab >= 0 && ylab < N) ? zy : __builtin_nanf("");
     const float inv = 1.0f / (float)batch, rse = 1.0f / se;
+    my_d = (exv * rse - (mine ? 1.0f : 0.0f)) * inv;  // softmax - onehot, over the batch mean (0 past N)
+    my_o = zc;
 #pragma unroll
-    for (int c = 0; c < NP; ++c) {
-      zy = (c == ylab && c < N) ? z[c] : zy;
-      d2[c] = (ex[c] * rse - ((c == ylab && c < N) ? 1.0f : 0.0f)) * inv;  // softmax - onehot, over the batch mean
-      outv[c] = z[c];
-    }
+    for (int c = 0; c < NP; ++c) d2[c] = pyz_readlane(my_d, c < 16 ? c : 0);
     lm = lse - zy;
   } else {
-    const float *y = reinterpret_cast<const float *>(g.y) + yrow * N;
-    const float sc = 2.0f / ((float)batch * (float)N);
-    const int act = g.act_last;
-    float a = 0.0f;
+    float outv[NP];
+    if (g.loss == PYZ_LOSS_SCCE) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) mx = fmaxf(mx, c < N ? z[c] : -3.0e38f);
+      float ex[NP], se = 0.0f;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        ex[c] = c < N ? expf(z[c] - mx) : 0.0f;
+        se += ex[c];
+      }
+      const float lse = mx + logf(se);
+      float zy = __builtin_nanf("");
+      const float inv = 1.0f / (float)batch, rse = 1.0f / se;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        zy = (c == ylab && c < N) ? z[c] : zy;
+        d2[c] = (ex[c] * rse - ((c == ylab && c < N) ? 1.0f : 0.0f)) * inv;  // softmax - onehot, over the batch mean
+        outv[c] = z[c];
+      }
+      lm = lse - zy;
+    } else {
+      const float *y = reinterpret_cast<const float *>(g.y) + yrow * N;
+      const float sc = 2.0f / ((float)batch * (float)N);
+      const int act = g.act_last;
+      float a = 0.0f;
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        const float o = pyz_act(z[c], act);
+        const float e = o - y[min(c, N - 1)];
+        a += c < N ? e * e : 0.0f;
+        d2[c] = c < N ? sc * e * pyz_act_grad(o, act) : 0.0f;
+        outv[c] = o;
+      }
+      lm = a / (float)N;
+    }
+    // lane c stores column c of the row
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
-      const float o = pyz_act(z[c], act);
-      const float e = o - y[min(c, N - 1)];
-      a += c < N ? e * e : 0.0f;
-      d2[c] = c < N ? sc * e * pyz_act_grad(o, act) : 0.0f;
-      outv[c] = o;
+      my_d = (l == c) ? d2[c] : my_d;
+      my_o = (l == c) ? outv[c] : my_o;
     }
-    lm = a / (float)N;
   }
   PYZ_STAMP(1, 3);
-  // lane c stores column c of the row
-  float my_d = 0.0f, my_o = 0.0f;
-#pragma unroll
-  for (int c = 0; c < NP; ++c) {
-    my_d = (l == c) ? d2[c] : my_d;
-    my_o = (l == c) ? outv[c] : my_o;
-  }
   if (l < N) {
     if (g.out_last) g.out_last[p * g.last_pstride + (long long)m * N + l] = my_o;
     if (g.delta_last) g.delta_last[p * g.last_pstride + (long long)m * N + l] = my_d;
