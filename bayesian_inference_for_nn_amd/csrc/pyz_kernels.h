@@ -787,15 +787,18 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
     const int i = g.row0 + il;
     const double *kr = kmat + il * 64;
     const float xi = g.all[(long long)i * g.D + d];
-    // every j, in order: a vanished kernel value or j == i adds an exact zero (k_svgd_update skips those
-    // rows to save their reads; here the rows are already in registers)
-    // four interleaved partial sums (j mod 4), combined in a fixed order: a single chain of 64 dependent
-    // float64 FMAs would run at their latency, not their rate
+    // sum_j K_ij (x_i - x_j) = x_i sum_j K_ij - sum_j K_ij x_j: one float64 FMA per (i, j) instead of a
+    // subtraction and an FMA (the kernel is float64-VALU-bound); float64 leaves ~1e-16 |x_i| sum_j K_ij of
+    // cancellation error, far below float32 phi.  Four interleaved partial sums (j mod 4), combined in a fixed
+    // order: a single chain of 64 dependent float64 FMAs would run at their latency, not their rate
     const double xid = (double)xi;
-    double r4[4] = {0.0, 0.0, 0.0, 0.0};
+    double r4[4] = {0.0, 0.0, 0.0, 0.0}, k4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 64; ++j) r4[j & 3] += kr[j] * (xid - xj[j]);
-    double rep = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+    for (int j = 0; j < 64; ++j) {
+      r4[j & 3] += kr[j] * xj[j];
+      k4[j & 3] += kr[j];          // (wave-uniform: scalar-side work)
+    }
+    double rep = xid * ((k4[0] + k4[1]) + (k4[2] + k4[3])) - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
     rep *= 2.0 * (double)g.gamma;
     const long long o = (long long)il * g.D + d;
     const float phi = (ksum[il] * g.grad[o] + (float)rep) / (float)g.M;
