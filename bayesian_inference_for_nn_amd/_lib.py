@@ -54,6 +54,7 @@ SIGNATURES = {
     "pyz_sample_normal_rows": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _u64, _u32, _u32, _p]),
     "pyz_fill_normal": (C.c_int, [_p, _i64, _u64, _u32, _u32, _f, _f, _p]),
     "pyz_debug_stamps": (C.c_int, [C.POINTER(C.c_uint64), _i64]),
+    "pyz_debug_mfma_f64_layout": (C.c_int, [C.POINTER(C.c_int32)]),
     "pyz_bench_dense_kernel": (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_int, _p, _p, C.c_int, _p, C.c_int, _p]),
 }
 

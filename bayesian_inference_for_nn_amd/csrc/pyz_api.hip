@@ -1124,6 +1124,26 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   return PYZ_OK;
 }
 
+// one-time check of the lane layout k_svgd_gram_tile assumes for v_mfma_f64_16x16x4_f64
+static bool mfma_f64_layout_ok(hipStream_t st) {
+  static int state = -1;  // -1 unknown, 0 no, 1 yes
+  if (state >= 0) return state == 1;
+  int *d = nullptr;
+  int h[512];
+  state = 0;
+  if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_probe_mfma_f64, dim3(1), dim3(64), 0, st, d);
+  if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+    bool ok = true;
+    for (int l = 0; l < 64 && ok; ++l)
+      for (int r = 0; r < 4; ++r)
+        if (h[4 * l + r] != (l >> 4) + 4 * r || h[256 + 4 * l + r] != (l & 15)) ok = false;
+    state = ok ? 1 : 0;
+  }
+  (void)hipFree(d);
+  return state == 1;
+}
+
 // ---------------------------------------------------------------- V2-V4
 int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
                   float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y, const int32_t *d_row_idx,
@@ -1190,12 +1210,21 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     ta.gamma = gamma;
     ta.range = PYZ_SV_E * cdiv(m->D, 256LL * PYZ_SV_E);  // one round of workgroups on the 256 CUs
     ta.nblk = cdiv(m->D, ta.range);
-    const size_t n_part = (size_t)n_local * ta.nblk * 64, n_k = (size_t)n_local * 64;
-    if ((rc = need_part2(m, n_part + n_k + n_local + 8))) return rc;
+    const size_t n_part = (size_t)n_local * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
+    if ((rc = need_part2(m, n_part + n_k + n_local + n_diag + 8))) return rc;
     ta.part = full(m)->x.part2;
     ta.kmat = ta.part + n_part;
     ta.ksum = reinterpret_cast<float *>(ta.kmat + n_k);
-    hipLaunchKernelGGL(k_svgd_dist_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+    // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
+    // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
+    const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
+    if (gram_on && mfma_f64_layout_ok(st)) {
+      ta.diag = ta.kmat + n_k + (n_local + 1) / 2 + 1;
+      hipLaunchKernelGGL(k_svgd_gram_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+    } else {
+      ta.diag = nullptr;
+      hipLaunchKernelGGL(k_svgd_dist_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+    }
     hipLaunchKernelGGL(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta);
     hipLaunchKernelGGL(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum);
   } else if (sweep == PYZ_SWEEP_JACOBI) {
@@ -1343,6 +1372,17 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
     else launch_wgrad_all(m, P, d_x, d_row_idx, batch, m->ctl, u, st, nullptr);  // the launch the step uses (all layers)
   }
   PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+int pyz_debug_mfma_f64_layout(int32_t *h_out512) {
+  if (!h_out512) return pyz_fail(PYZ_E_INVALID, "null pointer");
+  int *d = nullptr;
+  PYZ_HIP(hipMalloc((void **)&d, 512 * sizeof(int)));
+  hipLaunchKernelGGL(k_probe_mfma_f64, dim3(1), dim3(64), 0, nullptr, d);
+  const hipError_t e = hipMemcpy(h_out512, d, 512 * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PYZ_HIP(e);
   return PYZ_OK;
 }
 

@@ -649,6 +649,7 @@ struct SvgdTileArgs {
   int range;               // elements of D per workgroup of k_svgd_dist_tile (multiple of PYZ_SV_E)
   double *kmat;            // (n_local, 64) kernel values (0 past M)
   float *ksum;             // (n_local)
+  double *diag;            // Gram form only: (nblk, 64) partial squared norms of all particles; else nullptr
 };
 
 __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
@@ -744,22 +745,139 @@ __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
 
 // one workgroup per local row: d_ij = sum of the row's partials (four interleaved slices of the blocks, each
 // in block order, combined in a fixed order), K_ij, sum_j K_ij (float, j ascending)
+// Gram form of the distance pass on the float64 matrix cores: G = X X^T over the workgroup's range of D with
+// v_mfma_f64_16x16x4_f64 (float32 inputs converted exactly; their products are exact in float64, only the
+// sums round), the squared distances follow in k_svgd_kmat.  Same staging as k_svgd_dist_tile; wave w takes
+// elements 32 w .. 32 w + 31 of each slab (8 reduction steps of 4), the four partial Grams are added through
+// LDS in wave order.  The pairwise float64 VALU form above is 128 us at C5; this one is bound by the read of
+// the matrix.  Lane layout of the instruction (checked once per process by k_probe_mfma_f64):
+//   A: row = lane % 16, k = lane / 16;  B: k = lane / 16, col = lane % 16;  D[r]: row = lane / 16 + 4 r, col = lane % 16
+//   (not the 4 (lane / 16) + r of the float32 16x16x4 instruction).
+typedef double pyz_f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_probe_mfma_f64(int *out) {  // out[0..255]: row of D[r] per lane, out[256..511]: column
+  const int l = threadIdx.x & 63;
+  pyz_f64x4 c = {0.0, 0.0, 0.0, 0.0};
+  const pyz_f64x4 dr = __builtin_amdgcn_mfma_f64_16x16x4f64((l >> 4) == 0 ? (double)(l & 15) : 0.0, (l >> 4) == 0 ? 1.0 : 0.0, c, 0, 0, 0);
+  const pyz_f64x4 dc = __builtin_amdgcn_mfma_f64_16x16x4f64((l >> 4) == 0 ? 1.0 : 0.0, (l >> 4) == 0 ? (double)(l & 15) : 0.0, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    out[4 * l + r] = (int)dr[r];
+    out[256 + 4 * l + r] = (int)dc[r];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
+  __shared__ double gbuf[4096];                                  // the 64 x 64 Gram at the end ...
+  float (*xs)[64] = reinterpret_cast<float (*)[64]>(gbuf);       // ... and the staged slab [element][particle] before
+  const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;
+  const long long base = (long long)blockIdx.x * g.range;
+  const bool vec_ok = (g.D % 4 == 0);
+  pyz_f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = pyz_f64x4{0.0, 0.0, 0.0, 0.0};
+  // lane = particle: each lane brings 8 x 16 bytes of its row per slab (wave w: elements 32 w .. 32 w + 31);
+  // the next slab is requested before the matrix instructions of the current one
+  const float *row = g.all + (long long)min(l, g.M - 1) * g.D;
+  auto fetch = [&](const long long e0, float4 (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long long d = e0 + 32 * w + 4 * q;
+      if (l < g.M && vec_ok && d + 3 < g.D) {
+        v[q] = *reinterpret_cast<const float4 *>(row + d);
+      } else {
+        v[q].x = (l < g.M && d + 0 < g.D) ? row[d + 0] : 0.0f;
+        v[q].y = (l < g.M && d + 1 < g.D) ? row[d + 1] : 0.0f;
+        v[q].z = (l < g.M && d + 2 < g.D) ? row[d + 2] : 0.0f;
+        v[q].w = (l < g.M && d + 3 < g.D) ? row[d + 3] : 0.0f;
+      }
+    }
+  };
+  const int n_slabs = g.range / PYZ_SV_E;
+  float4 v[8];
+  if (base < g.D) fetch(base, v);
+  for (int ps = 0; ps < n_slabs; ++ps) {
+    const long long e0 = base + (long long)ps * PYZ_SV_E;
+    if (e0 >= g.D) break;  // uniform
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = 32 * w + 4 * q;
+      xs[e + 0][l] = v[q].x;
+      xs[e + 1][l] = v[q].y;
+      xs[e + 2][l] = v[q].z;
+      xs[e + 3][l] = v[q].w;
+    }
+    __syncthreads();
+    if (ps + 1 < n_slabs && e0 + PYZ_SV_E < g.D) fetch(e0 + PYZ_SV_E, v);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float *xe = xs[32 * w + 4 * ks + (l >> 4)];
+      double a[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) a[b] = (double)xe[(l & 15) + 16 * b];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = rb; cb < 4; ++cb)   // G is symmetric bit for bit: the 10 blocks on and above the diagonal
+          acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], a[cb], acc[rb][cb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // the four waves' partial Grams, added in wave order (the slab is dead: its storage holds G now)
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = rb; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gi = 16 * rb + (l >> 4) + 4 * r, gj = 16 * cb + (l & 15);
+            const double vsum = (ww == 0 ? 0.0 : gbuf[gi * 64 + gj]) + acc[rb][cb][r];
+            gbuf[gi * 64 + gj] = vsum;
+            if (cb != rb) gbuf[gj * 64 + gi] = vsum;   // the mirrored block
+          }
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < g.n_local * 64; e += 256) {
+    const int il = e >> 6, j = e & 63;
+    g.part[((long long)il * g.nblk + blockIdx.x) * 64 + j] = gbuf[(g.row0 + il) * 64 + j];
+  }
+  if (t < 64) g.diag[(long long)blockIdx.x * 64 + t] = gbuf[t * 64 + t];
+}
+
 __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g) {
-  __shared__ double sl[4][64];
+  __shared__ double sl[4][64], sg[4][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
   const double *pp = g.part + (long long)il * g.nblk * 64 + j;
-  double s = 0.0;
+  double s = 0.0, sn = 0.0;
   for (int b0 = q; b0 < g.nblk; b0 += 32) {
-    double v[8];
+    double v[8], n[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
+    for (int u = 0; u < 8; ++u) {
+      v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
+      n[u] = (g.diag && b0 + 4 * u < g.nblk) ? g.diag[(long long)(b0 + 4 * u) * 64 + j] : 0.0;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 8; ++u) {
+      s += v[u];
+      sn += n[u];
+    }
   }
   sl[q][j] = s;
+  sg[q][j] = sn;
   __syncthreads();
   if (q != 0) return;
-  const double d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
+  double d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
+  if (g.diag) {  // Gram form: the partials are inner products; d_ij = |x_i|^2 + |x_j|^2 - 2 x_i . x_j (d_ii = 0 exactly)
+    const int i = g.row0 + il;
+    const double nj = (sg[0][j] + sg[1][j]) + (sg[2][j] + sg[3][j]);
+    const double ni = (sg[0][i] + sg[1][i]) + (sg[2][i] + sg[3][i]);
+    d = (j == i) ? 0.0 : fmax((ni + nj) - 2.0 * d, 0.0);
+  }
   const double k = j < g.M ? exp(-(double)g.gamma * d) : 0.0;
   g.kmat[il * 64 + j] = k;
   float ks = 0.0f;

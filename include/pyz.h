@@ -192,8 +192,8 @@ int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const
  * squared distances and the RBF kernel are evaluated in float64.  gamma > 0 is
  * the fixed bandwidth (reference: 1.0).  d_loss[0] = sum_i loss_i / M over the
  * local rows.  Under PYZ_SWEEP_JACOBI with M <= 64 and local rows in multiples of four (row0 too) the
- * sweep reads the particle matrix once per pass for all rows; a shard then gets bit-identical rows to the
- * whole-matrix call.  Under PYZ_SWEEP_GAUSS_SEIDEL with M <= 64 and D <= 196 608 the sweep is one launch
+ * sweep reads the particle matrix once per pass for all rows (squared distances through the Gram matrix on the
+ * float64 matrix cores); a shard then gets the rows of the whole-matrix call.  Under PYZ_SWEEP_GAUSS_SEIDEL with M <= 64 and D <= 196 608 the sweep is one launch
  * per particle that reads the matrix once (repulsion sum in float32: phi is a float32 quantity); otherwise
  * two launches per particle (repulsion sum in float64).  The paths agree within float32 rounding of phi. */
 int pyz_svgd_step(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total,
@@ -233,6 +233,11 @@ int pyz_bench_dense_kernel(pyz_mlp *mlp, int kind, int layer, const float *d_the
  * phase stamps {shader clock, 100 MHz clock} x 8 slots x 256 workgroups x 4 kernels to
  * h_out (uint64).  The shipped library returns PYZ_E_INVALID. */
 int pyz_debug_stamps(uint64_t *h_out, int64_t n_words);
+
+/* ---- diagnostic: the lane layout of v_mfma_f64_16x16x4_f64's result as probed on this device:
+ * h_out512[4 l + r] = row, h_out512[256 + 4 l + r] = column of register r of lane l (k_svgd_gram_tile runs only
+ * when it is row = l / 16 + 4 r, column = l % 16). */
+int pyz_debug_mfma_f64_layout(int32_t *h_out512);
 
 #ifdef __cplusplus
 }

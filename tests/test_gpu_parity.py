@@ -478,9 +478,12 @@ def test_svgd_jacobi_shard_equals_whole(eng):
     plan.close()
 
 
-def test_svgd_jacobi_tiled_sweep(eng):
-    """Local rows in multiples of 4 run the all-rows-at-once kernels (k_svgd_dist_tile / kmat / update_tile):
-    8 particles against the oracle, and rows [4, 8) as a shard == the same rows of the whole-matrix step."""
+@pytest.mark.parametrize("gram", [1, 0])
+def test_svgd_jacobi_tiled_sweep(eng, monkeypatch, gram):
+    """Local rows in multiples of 4 run the all-rows-at-once kernels (k_svgd_gram_tile on the float64 matrix
+    cores, or the pairwise k_svgd_dist_tile; kmat; update_tile): 8 particles against the oracle, and rows
+    [4, 8) as a shard == the same rows of the whole-matrix step."""
+    monkeypatch.setenv("PYZ_SVGD_GRAM", str(gram))
     spec, n = SPECS["wide3"]
     x, y, _ = make(spec, n, seed=55)
     D = spec.n_params
