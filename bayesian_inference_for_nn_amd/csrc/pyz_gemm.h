@@ -327,6 +327,107 @@ __global__ void k_dense_fwd(DenseArgs g) {
   PYZ_STAMP(0, 3);
 }
 
+// ---------------------------------------------------------------- forward, LDS-tiled (many particles / samples)
+// The one-wave-per-tile kernel above pulls 200 KB of operands through L1 per 32 x 32 tile; with many particles
+// (or posterior samples) in one launch that is what bounds it (L2 -> L1 bandwidth), not the matrix pipe.  Here a
+// workgroup of four waves owns 128 rows x 32 NT columns: 16-deep slabs of both operands are staged in LDS
+// (A k-major so that the MFMA fragments are read with consecutive lanes; the two reduction halves of a fragment
+// sit 32 banks apart), the next slab travels global -> registers while the current one feeds NT MFMAs per A
+// fragment.  Operand bytes per 32 x 32 tile of output: 25 KB (NT = 7) instead of 200 KB.
+// Needs K % 4 == 0 with 16-byte aligned input rows, and an even N with 8-byte aligned [W; b] blocks (checked at
+// launch); exact fp32 as above.
+template <int NT>
+__global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
+  constexpr int BN = 32 * NT, BM = 128, BK = 16;
+  constexpr int AS = BM + 32;                          // row stride of As: the h = 1 half lands 32 banks further
+  constexpr int BS = (BN % 64 == 0) ? BN + 32 : BN;    // same for Bs
+  constexpr int BJ = NT;                               // 8-byte pieces of a B slab per thread (16 rows x BN / 2 = 256 NT):
+                                                       // a particle's [W; b] block is only 8-byte aligned in general
+  __shared__ __attribute__((aligned(16))) float As[2][BK][AS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BS];
+  const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63, r = l & 31, h = l >> 5;
+  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
+  const int batch = ctl.batch;
+  const int K = g.K, N = g.N;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  if (m0 >= batch) return;  // uniform
+  const int p = blockIdx.y;
+  // staging assignment.  A: thread -> row ra = t / 2 of the tile, two 16-byte pieces at k = 8 (t & 1) + {0, 4}
+  const int ra = t >> 1, ka = 8 * (t & 1);
+  const int ma = min(m0 + ra, batch - 1);
+  long long rowa = ma;
+  if (g.row_idx) rowa = g.row_idx[ctl.row_off + ma];
+  const float *ap = g.in + p * g.in_pstride + rowa * g.lda + ka;
+  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
+  float *gp = (g.gather_out && p == 0 && n0 == 0 && m0 + ra < batch) ? g.gather_out + (long long)ma * K + ka : nullptr;
+  float4 va[2];
+  float2 vb[BJ];
+  auto fetch = [&](const int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + ka + 4 * j;
+      va[j] = k < K ? *reinterpret_cast<const float4 *>(ap + k0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int idx = t + 256 * j, kr = idx / (BN / 2), c2 = idx % (BN / 2);
+      const int k = k0 + kr, n = n0 + 2 * c2;
+      vb[j] = (k < K && n < N) ? *reinterpret_cast<const float2 *>(wl + (long long)k * N + n) : make_float2(0.f, 0.f);
+    }
+  };
+  auto stage = [&](const int buf, const int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = ka + 4 * j;
+      As[buf][kk + 0][ra] = va[j].x;
+      As[buf][kk + 1][ra] = va[j].y;
+      As[buf][kk + 2][ra] = va[j].z;
+      As[buf][kk + 3][ra] = va[j].w;
+      if (gp && k0 + kk < K) *reinterpret_cast<float4 *>(gp + k0 + 4 * j) = va[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int idx = t + 256 * j, kr = idx / (BN / 2), c2 = idx % (BN / 2);
+      *reinterpret_cast<float2 *>(&Bs[buf][kr][2 * c2]) = vb[j];
+    }
+  };
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16{0};
+  const int ns = (K + BK - 1) / BK;
+  fetch(0);
+  stage(0, 0);
+  __syncthreads();
+  for (int s = 0; s < ns; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < ns) fetch((s + 1) * BK);
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      const float a = As[buf][2 * kp + h][32 * w + r];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = pyz_mfma(a, Bs[buf][2 * kp + h][32 * nt + r], acc[nt]);
+    }
+    if (s + 1 < ns) stage(buf ^ 1, (s + 1) * BK);
+    __syncthreads();
+  }
+  float *op = g.out + p * g.out_pstride;
+  const int act = g.act;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int nn = n0 + 32 * nt + r;
+    if (nn < N) {
+      const float bias = wl[(long long)K * N + nn];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int mm = m0 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (mm < batch) op[(long long)mm * N + nn] = pyz_act(acc[nt][i] + bias, act);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- data gradient
 // out[p][m][j] = ( sum_n delta[p][m][n] * W[j][n] ) * act'(hprev[p][m][j]),  j < K.
 // `in` = delta (row stride N), `aux` = previous layer's output (row stride K).
@@ -474,6 +575,21 @@ static inline int pyz_pick_waves(long long tiles, long long mfma_steps) {
 static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
   const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.N + 31) / 32);
   const int S = pyz_pick_waves(tiles * P, (g.K + 1) / 2 + 1);
+  // launches that fill the chip with one wave per tile (many particles / samples): the LDS-tiled kernel
+  const int lds_on = pyz_env_int("PYZ_FWD_LDS", 1);  // read per call: tests flip it
+  const bool lds_ok = g.K % 4 == 0 && g.N % 2 == 0 && g.lda % 4 == 0 && g.w_off % 2 == 0 && (P == 1 || g.theta_pstride % 2 == 0) &&
+                      (P == 1 || g.in_pstride % 4 == 0) && (reinterpret_cast<uintptr_t>(g.theta) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(g.in) & 15) == 0 &&
+                      (!g.gather_out || (reinterpret_cast<uintptr_t>(g.gather_out) & 15) == 0);
+  if (S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128) {
+    const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
+    const long long tl = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT));
+    const dim3 grid((unsigned)tl, P), block(256);
+    if (NT == 2) hipLaunchKernelGGL(k_dense_fwd_lds<2>, grid, block, 0, st, g);
+    else if (NT == 4) hipLaunchKernelGGL(k_dense_fwd_lds<4>, grid, block, 0, st, g);
+    else hipLaunchKernelGGL(k_dense_fwd_lds<7>, grid, block, 0, st, g);
+    return;
+  }
   hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }
 
