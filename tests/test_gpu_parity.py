@@ -132,6 +132,29 @@ def test_particles_and_row_gather(eng):
     plan.close()
 
 
+@pytest.mark.parametrize("lds", [1, 0])
+def test_wide_layers_many_particles(eng, monkeypatch, lds):
+    """64 particles on 128 -> 224 -> 10 with a gathered, ragged batch (250 of 256 rows): the launch fills the
+    chip with one tile per wave, so the forward pass of the wide layer runs as the LDS-tiled kernel
+    (k_dense_fwd_lds, 128 x 224 per workgroup) -- or, with the switch off, as the one-wave-per-tile kernel.
+    Losses and gradients of every particle against the oracle."""
+    monkeypatch.setenv("PYZ_FWD_LDS", str(lds))
+    spec = o_mlp.MLPSpec((128, 224, 10), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(77)
+    x = rng.normal(size=(400, 128)).astype(np.float32)
+    y = rng.integers(0, 10, size=400).astype(np.int32)
+    P, b = 64, 250
+    thetas = (rng.normal(size=(P, spec.n_params)) * 0.1).astype(np.float32)
+    idx = rng.permutation(400)[:b].astype(np.int32)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=256, max_particles=P)
+    loss, grad = plan.loss_grad(dev(thetas), dev(x), dev(y, torch.int32), batch=b, row_idx=dev(idx, torch.int32))
+    for p in (0, 1, 17, 63):
+        rl, rg, _ = o_mlp.loss_and_grad(thetas[p], x[idx], y[idx], spec)
+        close(loss[p:p + 1], [rl], what=f"loss[{p}]")
+        close(grad[p], rg, what=f"grad[{p}]")
+    plan.close()
+
+
 def test_full_size_mnist_gradient(eng):
     """BASELINE config 2 shapes: 784 -> 200 -> 10, batch 1024 (and the ragged 896)."""
     spec = o_mlp.MLPSpec((784, 200, 10), ("relu", "softmax"), "scce")
