@@ -346,7 +346,7 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   a.nblk = m->cur_nblk;
   a.tiles = tiles;
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
-  const dim3 grid((unsigned)tiles + 1, P);  // + the duties workgroup
+  const dim3 grid(pyz_pad8((long long)tiles + 1, P), P);  // + the duties workgroup (+ padding, see pyz_pad8)
   switch (S) {
     case 1: hipLaunchKernelGGL(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;

@@ -606,8 +606,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int r = l & 31, h = l >> 5;
   // workgroup `tiles` (the last id) owns no tile: its first wave does the duties of the step that do
   // not depend on the gradient, off the critical path of the tile workgroups
-  if (blockIdx.x == (unsigned)g.tiles) {
-    if (blockIdx.y == 0 && w == 0) pyz_step_duties(g, l);
+  if (blockIdx.x >= (unsigned)g.tiles) {  // (ids past `tiles` + 1 only pad the launch to a multiple of 8)
+    if (blockIdx.x == (unsigned)g.tiles && blockIdx.y == 0 && w == 0) pyz_step_duties(g, l);
     return;
   }
   const int tile = pyz_xcd_remap(blockIdx.x, g.tiles);

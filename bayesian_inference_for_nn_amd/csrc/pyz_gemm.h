@@ -350,9 +350,9 @@ __global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
   const int batch = ctl.batch;
   const int K = g.K, N = g.N;
   const int tiles_n = (N + BN - 1) / BN;
-  const int tile = blockIdx.x;
+  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  if (m0 >= batch) return;  // uniform
+  if (m0 >= batch) return;  // uniform (also the padding workgroups of the launch)
   const int p = blockIdx.y;
   // staging assignment.  A: thread -> row ra = t / 2 of the tile, two 16-byte pieces at k = 8 (t & 1) + {0, 4}
   const int ra = t >> 1, ka = 8 * (t & 1);
@@ -572,6 +572,12 @@ static inline int pyz_pick_waves(long long tiles, long long mfma_steps) {
   return S;
 }
 
+// grid.x in multiples of 8 when the launch has several particles: workgroups are dealt round-robin over the 8
+// XCDs by their LINEAR id, so only then does a tile id land on the same XCD (the same L2) for every particle --
+// with 79 row tiles per particle the rows an XCD touches shift from particle to particle and its L2 never keeps
+// them (predict, 100 draws x 10 000 rows: 18.0 ms; padded 14.6).  The padding workgroups own no tile.
+static inline unsigned pyz_pad8(long long n, int P) { return (unsigned)(P > 1 ? (n + 7) / 8 * 8 : n); }
+
 static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
   const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.N + 31) / 32);
   const int S = pyz_pick_waves(tiles * P, (g.K + 1) / 2 + 1);
@@ -581,22 +587,25 @@ static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hip
                       (P == 1 || g.in_pstride % 4 == 0) && (reinterpret_cast<uintptr_t>(g.theta) & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(g.in) & 15) == 0 &&
                       (!g.gather_out || (reinterpret_cast<uintptr_t>(g.gather_out) & 15) == 0);
-  if (S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128) {
+  // (measured: with few row tiles per particle -- C5: 8 -- the LDS kernel wins, 0.23 against 0.32 ms; with many --
+  // predict, 79 -- the one-wave kernel runs out of an L2 that keeps its slice of the rows and wins, 14.5 against 16.7 ms)
+  const int lds_max_rows = pyz_env_int("PYZ_FWD_LDS_MAXROWS", 2048);
+  if (S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows) {
     const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
     const long long tl = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT));
-    const dim3 grid((unsigned)tl, P), block(256);
+    const dim3 grid(pyz_pad8(tl, P), P), block(256);
     if (NT == 2) hipLaunchKernelGGL(k_dense_fwd_lds<2>, grid, block, 0, st, g);
     else if (NT == 4) hipLaunchKernelGGL(k_dense_fwd_lds<4>, grid, block, 0, st, g);
     else hipLaunchKernelGGL(k_dense_fwd_lds<7>, grid, block, 0, st, g);
     return;
   }
-  hipLaunchKernelGGL(k_dense_fwd, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+  hipLaunchKernelGGL(k_dense_fwd, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }
 
 static inline void pyz_launch_bwd_data(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
   const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.K + 31) / 32);
   const int S = pyz_pick_waves(tiles * P, (g.N + 1) / 2);
-  hipLaunchKernelGGL(k_dense_bwd_data, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+  hipLaunchKernelGGL(k_dense_bwd_data, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }
 
 static inline void pyz_launch_bwd_weight(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
