@@ -118,7 +118,7 @@ class BayesianModel:
         n = len(x)
         # bound the activation workspace: rows x samples per launch
         rows = min(n, 8192)
-        chunk_s = max(1, min(nb_samples, (1 << 24) // max(1, rows * max(self._model.dims))))
+        chunk_s = max(1, min(nb_samples, int(os.environ.get("PYZ_PREDICT_WS", 1 << 26)) // max(1, rows * max(self._model.dims))))
         if self._plan is None or self._plan.max_batch < rows or self._plan.max_particles < chunk_s:
             self._plan = MLPPlan(self._model.spec, max_batch=rows, max_particles=chunk_s)
         xd = torch.as_tensor(x).cuda()
