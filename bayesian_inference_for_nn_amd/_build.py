@@ -13,6 +13,10 @@ LIB = os.path.join(CSRC, "libpyz.so")
 SOURCES = ["pyz_api.hip"]
 
 
+class NoCompiler(RuntimeError):
+    """hipcc is not installed (as opposed to: hipcc ran and failed)."""
+
+
 def _inputs():
     """Everything the library is compiled from: the translation unit, every header beside it, the C-ABI header."""
     return ([os.path.join(CSRC, f) for f in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) +
@@ -34,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build the gfx950 library")
+        raise NoCompiler("hipcc not found: cannot build the gfx950 library")
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:

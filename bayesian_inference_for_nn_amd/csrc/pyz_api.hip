@@ -37,9 +37,11 @@ struct Extra {  // lazily sized buffers kept beside the plan
   hipGraphExec_t hm_exec = nullptr;
   unsigned long long hm_key = 0;
   double *part2 = nullptr;
-  size_t tab_cap_bytes = 0;
-  void *tab_host = nullptr;  // pinned
-  size_t tab_host_cap = 0;
+  // per-run tables go up through two pinned buffers used in turn (an event each: rewritten only once its copy has left)
+  void *tab_host = nullptr;
+  size_t tab_host_cap = 0;  // bytes per buffer
+  hipEvent_t tab_ev[2] = {};
+  unsigned long long tab_count = 0;
   // per-proposal HMC scalars (uniforms + HmcCall) go up through a ring of pinned slots: a copy from pageable
   // memory would make every pyz_hmc_step wait for the stream, i.e. serialise the host with the device
   static constexpr int UP_SLOTS = 64;
@@ -59,6 +61,16 @@ struct pyz_mlp_full : pyz_mlp {
 namespace {
 
 inline pyz_mlp_full *full(pyz_mlp *m) { return static_cast<pyz_mlp_full *>(m); }
+
+void drop_graphs(pyz_mlp *m) {
+  for (int c = 0; c < PYZ_GRAPH_CHUNKS; ++c) {
+    if (m->graph_exec[c]) (void)hipGraphExecDestroy(m->graph_exec[c]);
+    if (m->graph[c]) (void)hipGraphDestroy(m->graph[c]);
+    m->graph_exec[c] = nullptr;
+    m->graph[c] = nullptr;
+    m->graph_len[c] = 0;
+  }
+}
 
 int need_grad(pyz_mlp *m, int P) {
   return ensure_bytes((void **)&m->grad, &full(m)->x.grad_cap, sizeof(float) * (size_t)P * m->D + 64, m);
@@ -90,7 +102,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
             int slot0 = 0) {
   m->pend_on = false;
-  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
+  PYZ_LAUNCH(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -107,7 +119,7 @@ void set_ctl_lazy(pyz_mlp *m, int batch, float lr, long long n) {
 void flush_ctl(pyz_mlp *m, hipStream_t st) {
   if (!m->pend_on) return;
   m->pend_on = false;
-  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl, m->pend.batch, m->pend.lr, m->pend.n, m->pend.row_off, m->pend.i,
+  PYZ_LAUNCH(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl, m->pend.batch, m->pend.lr, m->pend.n, m->pend.row_off, m->pend.i,
                      m->pend.slot0);
 }
 
@@ -165,9 +177,9 @@ void launch_loss(pyz_mlp *m, int P, const void *y, const int32_t *row_idx, int g
   // partial slots of blocks past grid_batch must read as zero: the finalisers sum nblk of them
   if ((int)grid.x < g.nblk) g.nblk = grid.x;
   if (m->loss == PYZ_LOSS_SCCE)
-    hipLaunchKernelGGL(k_loss_scce, grid, dim3(256), 0, st, g);
+    PYZ_LAUNCH(k_loss_scce, grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL(k_loss_mse, grid, dim3(256), 0, st, g);
+    PYZ_LAUNCH(k_loss_mse, grid, dim3(256), 0, st, g);
 }
 
 inline int loss_nblk(const pyz_mlp *m, int grid_batch) { return std::min(cdiv(m->max_batch, 256), cdiv(grid_batch, 256)); }
@@ -275,7 +287,7 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
     m->cur_nblk = g.nblk;
     const dim3 grid((unsigned)cdiv(grid_batch, 4), P), block(256);
 #define PYZ_HEAD_ROWS_CASE(U, C) \
-  if (UT == U && NP == C) { hipLaunchKernelGGL((k_head_rows<U, C>), grid, block, 0, st, g); return; }
+  if (UT == U && NP == C) { PYZ_LAUNCH((k_head_rows<U, C>), grid, block, 0, st, g); return; }
     PYZ_HEAD_ROWS_CASE(1, 4) PYZ_HEAD_ROWS_CASE(1, 8) PYZ_HEAD_ROWS_CASE(1, 12) PYZ_HEAD_ROWS_CASE(1, 16)
     PYZ_HEAD_ROWS_CASE(1, 24) PYZ_HEAD_ROWS_CASE(1, 32)
     PYZ_HEAD_ROWS_CASE(4, 4) PYZ_HEAD_ROWS_CASE(4, 8) PYZ_HEAD_ROWS_CASE(4, 12) PYZ_HEAD_ROWS_CASE(4, 16)
@@ -287,7 +299,7 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   g.nblk = cdiv(grid_batch, 32);
   m->cur_nblk = g.nblk;
   static const int head_waves = pyz_env_int("PYZ_HEAD_WAVES", 8) >= 8 ? 8 : 4;
-  hipLaunchKernelGGL(k_head, dim3(g.nblk, P), dim3(64 * head_waves), head_waves * 4096 + 2 * 32 * 33 * 4 + 64, st, g);
+  PYZ_LAUNCH(k_head, dim3(g.nblk, P), dim3(64 * head_waves), head_waves * 4096 + 2 * 32 * 33 * 4 + 64, st, g);
 }
 
 // data gradients of layers L-2 .. 1 (the head already produced delta[L-2])
@@ -345,14 +357,15 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   a.part = m->part;
   a.nblk = m->cur_nblk;
   a.tiles = tiles;
+  a.nonfinite = m->nonfinite;
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
   const dim3 grid(pyz_pad8((long long)tiles + 1, P), P);  // + the duties workgroup (+ padding, see pyz_pad8)
   switch (S) {
-    case 1: hipLaunchKernelGGL(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;
-    case 4: hipLaunchKernelGGL(k_wgrad_all<4>, grid, dim3(256), 4 * 4096, st, a); break;
-    case 8: hipLaunchKernelGGL(k_wgrad_all<8>, grid, dim3(512), 8 * 4096, st, a); break;
-    default: hipLaunchKernelGGL(k_wgrad_all<16>, grid, dim3(1024), 16 * 4096, st, a); break;
+    case 1: PYZ_LAUNCH(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
+    case 2: PYZ_LAUNCH(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;
+    case 4: PYZ_LAUNCH(k_wgrad_all<4>, grid, dim3(256), 4 * 4096, st, a); break;
+    case 8: PYZ_LAUNCH(k_wgrad_all<8>, grid, dim3(512), 8 * 4096, st, a); break;
+    default: PYZ_LAUNCH(k_wgrad_all<16>, grid, dim3(1024), 16 * 4096, st, a); break;
   }
 }
 
@@ -363,17 +376,12 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
   if (can_fuse(m)) {
     static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 1);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
-    hipEvent_t *ev = m->probe;  // measurement only (pyz_sgld_profile)
-    if (ev) (void)hipEventRecord(ev[0], st);
     launch_forward_hidden(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb);
-    if (ev) (void)hipEventRecord(ev[1], st);
     launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
-    if (ev) (void)hipEventRecord(ev[2], st);
     if (want_grad) {
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
       launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xb);
     }
-    if (ev) (void)hipEventRecord(ev[3], st);
     return;
   }
   flush_ctl(m, st);
@@ -463,6 +471,8 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     if (hipMalloc((void **)&m->xb, bytes) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
     m->ws_bytes += bytes;
   }
+  if (hipMalloc((void **)&m->nonfinite, 64) != hipSuccess || hipMemset(m->nonfinite, 0, 64) != hipSuccess)
+    return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
   if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
   if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
   const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
@@ -479,18 +489,20 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
 int pyz_mlp_destroy(pyz_mlp *mm) {
   if (!mm) return PYZ_OK;
   pyz_mlp_full *m = full(mm);
-  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-  if (m->graph) (void)hipGraphDestroy(m->graph);
+  drop_graphs(m);
   if (m->x.hm_exec) (void)hipGraphExecDestroy(m->x.hm_exec);
   if (m->x.hm_graph) (void)hipGraphDestroy(m->x.hm_graph);
   for (int l = 0; l < PYZ_MAX_LAYERS; ++l) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->tab_lr, m->xb, m->x.hm_buf};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  if (m->x.tab_host) (void)hipHostFree(m->x.tab_host);
+  if (m->x.tab_host) {
+    (void)hipHostFree(m->x.tab_host);
+    for (auto &e : m->x.tab_ev) (void)hipEventDestroy(e);
+  }
   if (m->x.up_host) {
     (void)hipHostFree(m->x.up_host);
     for (auto &e : m->x.up_ev) (void)hipEventDestroy(e);
@@ -513,7 +525,7 @@ int pyz_mlp_forward(pyz_mlp *m, const float *d_theta, int P, const float *d_x, c
   if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
   launch_forward(m, d_theta, m->D, P, d_x, d_row_idx, batch, m->ctl, st);
   const int C = m->dims[m->L];
-  hipLaunchKernelGGL(k_forward_finish, dim3(cdiv(batch, 256), P), dim3(256), 0, st, m->act[m->L - 1],
+  PYZ_LAUNCH(k_forward_finish, dim3(cdiv(batch, 256), P), dim3(256), 0, st, m->act[m->L - 1],
                      (long long)m->max_batch * C, C, m->acts[m->L - 1] == PYZ_ACT_SOFTMAX ? 1 : 0, batch, d_out);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -533,7 +545,7 @@ int pyz_mlp_loss_grad(pyz_mlp *m, const float *d_theta, int P, const float *d_x,
   u.grad = d_grad;
   u.grad_pstride = m->D;
   launch_loss_backward(m, d_theta, m->D, P, d_x, d_y, d_row_idx, batch, m->ctl, d_grad != nullptr, u, st);
-  hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, d_loss);
+  PYZ_LAUNCH(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, d_loss, m->nonfinite);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -561,8 +573,8 @@ int pyz_sgd_step(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, 
   }
   launch_loss_backward(m, d_theta, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
   if (!fused)
-    hipLaunchKernelGGL(k_sgd_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, m->grad, m->D, m->ctl, m->part,
-                       m->cur_nblk, d_loss);
+    PYZ_LAUNCH(k_sgd_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, m->grad, m->D, m->ctl, m->part,
+                       m->cur_nblk, d_loss, m->nonfinite);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -596,8 +608,8 @@ int pyz_swag_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, f
   }
   launch_loss_backward(m, d_theta, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
   if (!fused)
-    hipLaunchKernelGGL(k_swag_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, d_mean, d_sq_mean, d_dev_row,
-                       m->grad, m->D, update_moments ? 1 : 0, m->ctl, m->part, m->cur_nblk, d_loss);
+    PYZ_LAUNCH(k_swag_update, dim3(cdiv(m->D, 256)), dim3(256), 0, st, d_theta, d_mean, d_sq_mean, d_dev_row,
+                       m->grad, m->D, update_moments ? 1 : 0, m->ctl, m->part, m->cur_nblk, d_loss, m->nonfinite);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -658,7 +670,8 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
   a.nblk = m->cur_nblk;
   a.loss = loss;
   a.loss_indexed = chained ? 1 : 0;
-  hipLaunchKernelGGL(k_sgld_update, dim3(cdiv(cdiv(m->D, 4), 256)), dim3(256), 0, st, a);
+  a.nonfinite = m->nonfinite;
+  PYZ_LAUNCH(k_sgld_update, dim3(cdiv(cdiv(m->D, 4), 256)), dim3(256), 0, st, a);
 }
 
 int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
@@ -680,7 +693,6 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
 static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
                          const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
                          int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream,
-                         hipEvent_t *events /* optional: 4 per step, recorded around the kernels (eager only) */,
                          int mode = PYZ_UPD_SGLD, const SwagChain *swag = nullptr) {
   if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
   if (mode != PYZ_UPD_SGLD && !can_fuse(m))
@@ -701,46 +713,64 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   pyz_mlp_full *f = full(m);
   hipStream_t st = as_stream(stream);
-  // per-run tables (one padding entry: the last step prepares a slot nobody reads)
+  // per-run tables (one padding entry: the last step prepares a slot nobody reads); batch sizes and learning
+  // rates share one device allocation
   const size_t n_tab = (size_t)n_steps + 1;
   if (m->tab_cap < (int)n_tab) {
-    const size_t cap = std::max<size_t>(n_tab, 65536);  // generous: the table pointers are baked into the graph
+    const size_t cap = std::max<size_t>(n_tab, 65536);  // generous: the table pointers are baked into the graphs
     if (m->tab_bs) PYZ_HIP(hipFree(m->tab_bs));
-    if (m->tab_lr) PYZ_HIP(hipFree(m->tab_lr));
     m->tab_bs = nullptr;
     m->tab_lr = nullptr;
-    PYZ_HIP(hipMalloc((void **)&m->tab_bs, sizeof(int32_t) * cap));
-    PYZ_HIP(hipMalloc((void **)&m->tab_lr, sizeof(float) * cap));
+    PYZ_HIP(hipMalloc((void **)&m->tab_bs, 8 * cap));
+    m->tab_lr = reinterpret_cast<float *>(m->tab_bs + cap);
     m->tab_cap = (int)cap;
-    // table pointers are baked into a captured graph
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    drop_graphs(m);
   }
+  // the tables go up through two pinned buffers used in turn: a buffer is rewritten once the copy of the run
+  // before the previous one has left it (no stream-wide synchronisation per call)
   if (f->x.tab_host_cap < 8 * n_tab) {
-    if (f->x.tab_host) PYZ_HIP(hipHostFree(f->x.tab_host));
-    f->x.tab_host = nullptr;
-    PYZ_HIP(hipHostMalloc(&f->x.tab_host, 8 * n_tab));
-    f->x.tab_host_cap = 8 * n_tab;
+    if (f->x.tab_host) {
+      PYZ_HIP(hipStreamSynchronize(st));
+      PYZ_HIP(hipHostFree(f->x.tab_host));
+      f->x.tab_host = nullptr;
+    } else {
+      for (auto &e : f->x.tab_ev) PYZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t cap = std::max<size_t>(8 * n_tab, 8 * 4096);
+    PYZ_HIP(hipHostMalloc(&f->x.tab_host, 2 * cap));
+    f->x.tab_host_cap = cap;
+    f->x.tab_count = 0;
   }
-  // the previous run's copies must have left the pinned buffer before it is rewritten
-  PYZ_HIP(hipStreamSynchronize(st));
-  int32_t *hb = reinterpret_cast<int32_t *>(f->x.tab_host);
-  float *hl = reinterpret_cast<float *>(hb + n_tab);
-  std::memcpy(hb, h_batch_sizes, sizeof(int32_t) * n_steps);
-  std::memcpy(hl, h_lr, sizeof(float) * n_steps);
-  hb[n_steps] = h_batch_sizes[n_steps - 1];
-  hl[n_steps] = h_lr[n_steps - 1];
-  PYZ_HIP(hipMemcpyAsync(m->tab_bs, hb, sizeof(int32_t) * n_tab, hipMemcpyHostToDevice, st));
-  PYZ_HIP(hipMemcpyAsync(m->tab_lr, hl, sizeof(float) * n_tab, hipMemcpyHostToDevice, st));
+  {
+    const unsigned slot = (unsigned)(f->x.tab_count & 1);
+    if (f->x.tab_count >= 2) PYZ_HIP(hipEventSynchronize(f->x.tab_ev[slot]));
+    ++f->x.tab_count;
+    int32_t *hb = reinterpret_cast<int32_t *>(static_cast<unsigned char *>(f->x.tab_host) + slot * f->x.tab_host_cap);
+    float *hl = reinterpret_cast<float *>(hb + n_tab);
+    std::memcpy(hb, h_batch_sizes, sizeof(int32_t) * n_steps);
+    std::memcpy(hl, h_lr, sizeof(float) * n_steps);
+    hb[n_steps] = h_batch_sizes[n_steps - 1];
+    hl[n_steps] = h_lr[n_steps - 1];
+    PYZ_HIP(hipMemcpyAsync(m->tab_bs, hb, sizeof(int32_t) * n_tab, hipMemcpyHostToDevice, st));
+    PYZ_HIP(hipMemcpyAsync(m->tab_lr, hl, sizeof(float) * n_tab, hipMemcpyHostToDevice, st));
+    PYZ_HIP(hipEventRecord(f->x.tab_ev[slot], st));
+  }
   const long long row_stride = m->max_batch;
   if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0))) return rc;
 
   int s = 0;
-  // steps per captured graph (even: the StepCtl ping-pong returns to slot 0); a replay costs a
-  // fixed ~8 us gap, so more steps per graph amortise it
-  static const int G = std::max(2, pyz_env_int("PYZ_GRAPH_STEPS", 32) & ~1);
-  if (use_graph && st != nullptr && n_steps >= G) {
-    // everything baked into the graph goes into the key
+  m->run_graph_steps = m->run_eager_steps = m->run_graph_launches = 0;
+  // A run of ANY length is replayed from captured graphs: chunks of G steps, then of the powers of two below G
+  // down to one step (a replay costs a fixed ~8 us gap, so long chunks first).  Every chunk starts on StepCtl
+  // slot 0: all lengths but the last (1) are even, and the ping-pong returns to slot 0 after an even count.
+  static const int G = std::min(128, std::max(2, pyz_env_int("PYZ_GRAPH_STEPS", 32) & ~1));
+  if (use_graph && st != nullptr && !pyz_probe().on) {
+    int lens[PYZ_GRAPH_CHUNKS], nl = 0;
+    lens[nl++] = G;
+    int c = 1;
+    while (2 * c < G) c *= 2;
+    for (; c >= 1 && nl < PYZ_GRAPH_CHUNKS; c >>= 1) lens[nl++] = c;
+    // everything baked into the graphs goes into the key
     unsigned long long key = 1469598103934665603ull;
     auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
     mix((unsigned long long)(uintptr_t)d_theta); mix((unsigned long long)(uintptr_t)d_mean);
@@ -748,28 +778,38 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
     mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
     mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G); mix((unsigned long long)mode);
+    mix((unsigned long long)(uintptr_t)st);
     if (swag) { mix((unsigned long long)(uintptr_t)swag->dev); mix((unsigned long long)swag->k); mix((unsigned long long)swag->freq); }
-    if (!m->graph_exec || m->graph_key != key) {
-      if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-      if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-      PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-      for (int k = 0; k < G; ++k)
-        launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
-                         nullptr, d_losses, st, mode, swag);
-      hipGraph_t gr = nullptr;
-      PYZ_HIP(hipStreamEndCapture(st, &gr));
-      m->graph = gr;
-      PYZ_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+    if (m->graph_key != key) {
+      drop_graphs(m);
       m->graph_key = key;
     }
-    for (; s + G <= n_steps; s += G) PYZ_HIP(hipGraphLaunch(m->graph_exec, st));
+    while (s < n_steps) {
+      int ci = 0;
+      while (lens[ci] > n_steps - s) ++ci;  // lens ends with 1: always found
+      const int len = lens[ci];
+      if (!m->graph_exec[ci]) {
+        PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        for (int k = 0; k < len; ++k)
+          launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
+                           nullptr, d_losses, st, mode, swag);
+        hipGraph_t gr = nullptr;
+        PYZ_HIP(hipStreamEndCapture(st, &gr));
+        m->graph[ci] = gr;
+        PYZ_HIP(hipGraphInstantiate(&m->graph_exec[ci], gr, nullptr, nullptr, 0));
+        m->graph_len[ci] = len;
+      }
+      PYZ_HIP(hipGraphLaunch(m->graph_exec[ci], st));
+      s += len;
+      m->run_graph_steps += len;
+      ++m->run_graph_launches;
+    }
   }
   for (; s < n_steps; ++s) {
-    m->probe = events ? events + 4 * (size_t)s : nullptr;
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
                      d_losses, st, mode, swag);
+    ++m->run_eager_steps;
   }
-  m->probe = nullptr;
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -778,7 +818,7 @@ int pyz_sgld_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, co
                  const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
                  int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream) {
   return sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, seed,
-                       d_losses, use_graph, stream, nullptr);
+                       d_losses, use_graph, stream);
 }
 
 // The SGD train loop (SGD.py:42-69 inside Optimizer.py:121-134) as one device-resident run: the launch sequence
@@ -787,7 +827,7 @@ int pyz_sgd_run(pyz_mlp *m, float *d_theta, const float *d_x, const void *d_y, c
                 const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t slot0, float *d_losses, int use_graph,
                 void *stream) {
   return sgld_run_impl(m, d_theta, d_theta, d_theta, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, 0, slot0, 0, d_losses,
-                       use_graph, stream, nullptr, PYZ_UPD_SGD);
+                       use_graph, stream, PYZ_UPD_SGD);
 }
 
 // The SWAG train loop (SWAG.py:43-94 inside Optimizer.py:121-134) as one device-resident run.  The moment / deviation
@@ -799,39 +839,7 @@ int pyz_swag_run(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, fl
   if (n0 < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
   const SwagChain sc{d_dev, k, frequency};
   return sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, 0, d_losses,
-                       use_graph, stream, nullptr, PYZ_UPD_SWAG, &sc);
-}
-
-// Measurement: n_steps eager SGLD steps with HIP events around the kernels of every step, on the
-// stream they are launched on.  h_avg_us[3] = average in-pipeline duration (microseconds, launch gap
-// included) of {hidden-layer forward kernels, k_head, data-gradient + k_wgrad_all}.  Same arguments
-// and effect on the chain as pyz_sgld_run.
-int pyz_sgld_profile(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
-                     const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
-                     int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, float *h_avg_us, void *stream) {
-  if (!m || !h_avg_us) return pyz_fail(PYZ_E_INVALID, "null argument");
-  if (!can_fuse(m)) return pyz_fail(PYZ_E_INVALID, "profile needs the fused step (last layer <= 32 wide)");
-  if (n_steps <= 0 || n_steps > 4096) return pyz_fail(PYZ_E_INVALID, "n_steps outside [1, 4096]");
-  hipStream_t st = as_stream(stream);
-  std::vector<hipEvent_t> ev((size_t)4 * n_steps);
-  for (auto &e : ev) PYZ_HIP(hipEventCreate(&e));
-  // one eager run of n_steps: the launches queue ahead of the GPU, so each kernel runs right behind
-  // its predecessor exactly as inside the replayed graph
-  int rc = sgld_run_impl(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, n0, slot0, seed,
-                         d_losses, 0, stream, ev.data());
-  if (rc == PYZ_OK && hipStreamSynchronize(st) != hipSuccess) rc = pyz_fail(PYZ_E_HIP, "stream synchronize failed");
-  double acc[3] = {0, 0, 0};
-  if (rc == PYZ_OK) {
-    for (int s = 0; s < n_steps; ++s)
-      for (int k = 0; k < 3; ++k) {
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, ev[4 * (size_t)s + k], ev[4 * (size_t)s + k + 1]);
-        acc[k] += ms;
-      }
-    for (int k = 0; k < 3; ++k) h_avg_us[k] = (float)(acc[k] * 1e3 / n_steps);
-  }
-  for (auto &e : ev) (void)hipEventDestroy(e);
-  return rc;
+                       use_graph, stream, PYZ_UPD_SWAG, &sc);
 }
 
 // ---------------------------------------------------------------- B2-B4
@@ -869,7 +877,7 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   a.nblk_loss = loss_nblk(m, batch);
   a.ctl = m->ctl;
   a.cost = d_cost;
-  hipLaunchKernelGGL(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
+  PYZ_LAUNCH(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
   WgradArgs u{};
   if (can_fuse(m)) {  // the mu / rho update runs in the epilogue of the weight-gradient kernel
     u.mode = PYZ_UPD_BBB;
@@ -895,7 +903,7 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
     u.grad_pstride = m->D;
     launch_loss_backward(m, d_w, m->D, 1, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
     a.nblk_loss = m->cur_nblk;
-    hipLaunchKernelGGL(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
+    PYZ_LAUNCH(k_bbb_update, dim3(nblk_kl), dim3(256), 0, st, a);
   }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -1030,9 +1038,9 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
         auto launch_all = [&]() {
           for (int t = 0; t <= L; ++t) {
             mm.t = t;
-            hipLaunchKernelGGL(kmulti, dim3(NW, P), dim3(PYZ_HM_THREADS), mlds, st, mm);
+            PYZ_LAUNCH(kmulti, dim3(NW, P), dim3(PYZ_HM_THREADS), mlds, st, mm);
           }
-          hipLaunchKernelGGL(k_hmc_multi_final, dim3(P), dim3(PYZ_HM_THREADS), 0, st, mm);
+          PYZ_LAUNCH(k_hmc_multi_final, dim3(P), dim3(PYZ_HM_THREADS), 0, st, mm);
         };
         if (!use_graph || st == nullptr) {  // the legacy default stream cannot be captured
           launch_all();
@@ -1055,7 +1063,7 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
       }
       if (lds > 64 * 1024)
         PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3(P), dim3(PYZ_HF_THREADS), lds, st, f);
+      PYZ_LAUNCH(kern, dim3(P), dim3(PYZ_HF_THREADS), lds, st, f);
       PYZ_LAUNCH_CHECK();
       return PYZ_OK;
     }
@@ -1083,25 +1091,25 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
     u.grad = m->grad;
     u.grad_pstride = m->D;
     launch_loss_backward(m, d_q, m->D, P, d_x, d_y, nullptr, n_rows, m->ctl, true, u, st);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, loss);
+    PYZ_LAUNCH(k_loss_finalize, dim3(P), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, loss, m->nonfinite);
   };
   // momentum, snapshot, K0 and the prior part of U0
   a.nblk = nblk4;
-  hipLaunchKernelGGL(k_hmc_begin, dim3(nblk4, P), dim3(256), 0, st, a);
+  PYZ_LAUNCH(k_hmc_begin, dim3(nblk4, P), dim3(256), 0, st, a);
   grad_eval();
-  hipLaunchKernelGGL(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk4, loss, a.n_train, mass, energies, 0);
+  PYZ_LAUNCH(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk4, loss, a.n_train, mass, energies, 0);
   // half kick + first drift (HMC.py:82-84); with L == 0 the two half kicks share the gradient
   a.nblk = nblk1;
   if (L == 0) {
     a.kick1 = epsilon / 2;
     a.kick2 = epsilon / 2;
     a.drift = 0.0f;
-    hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+    PYZ_LAUNCH(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
   } else {
     a.kick1 = epsilon / 2;
     a.kick2 = 0.0f;
     a.drift = epsilon / mass;
-    hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+    PYZ_LAUNCH(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
     for (int i = 1; i <= L; ++i) {
       grad_eval();
       a.kick1 = epsilon;
@@ -1112,14 +1120,14 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
         a.kick2 = epsilon / 2;
         a.drift = 0.0f;
       }
-      hipLaunchKernelGGL(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
+      PYZ_LAUNCH(k_hmc_kick_drift, dim3(nblk1, P), dim3(256), 0, st, a);
     }
   }
   // K1, U1 (the loss of the last gradient evaluation is the loss at the proposal)
-  hipLaunchKernelGGL(k_hmc_end_energy, dim3(nblk1, P), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk1, loss, a.n_train, mass, energies, 1);
-  hipLaunchKernelGGL(k_hmc_accept, dim3(cdiv(P, 64)), dim3(64), 0, st, energies, unif, burning, d_stats, P);
-  hipLaunchKernelGGL(k_hmc_restore, dim3(nblk1, P), dim3(256), 0, st, d_q, m->qsave, d_stats, m->D);
+  PYZ_LAUNCH(k_hmc_end_energy, dim3(nblk1, P), dim3(256), 0, st, a);
+  PYZ_LAUNCH(k_hmc_energy_finalize, dim3(P), dim3(64), 0, st, f->x.part2, nblk1, loss, a.n_train, mass, energies, 1);
+  PYZ_LAUNCH(k_hmc_accept, dim3(cdiv(P, 64)), dim3(64), 0, st, energies, unif, burning, d_stats, P);
+  PYZ_LAUNCH(k_hmc_restore, dim3(nblk1, P), dim3(256), 0, st, d_q, m->qsave, d_stats, m->D);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -1132,7 +1140,7 @@ static bool mfma_f64_layout_ok(hipStream_t st) {
   int h[512];
   state = 0;
   if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return false;
-  hipLaunchKernelGGL(k_probe_mfma_f64, dim3(1), dim3(64), 0, st, d);
+  PYZ_LAUNCH(k_probe_mfma_f64, dim3(1), dim3(64), 0, st, d);
   if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
     bool ok = true;
     for (int l = 0; l < 64 && ok; ++l)
@@ -1145,36 +1153,47 @@ static bool mfma_f64_layout_ok(hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- V2-V4
-int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
-                  float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y, const int32_t *d_row_idx,
-                  int batch, float lr, float gamma, int64_t t, int sweep, float *d_loss, void *stream) {
+// phase 1 of SVGD.step: all loss gradients of the local particles in one particle-batched pass -- g_i depends on
+// particle i only (SVGD.py:104-111); they stay in the plan's gradient buffer, the losses in its scalars
+static int svgd_gradients_impl(pyz_mlp *m, const float *d_particles, int n_local, const float *d_x, const void *d_y,
+                               const int32_t *d_row_idx, int batch, hipStream_t st) {
   int rc = check_call(m, n_local, batch);
   if (rc) return rc;
   if ((rc = check_loss_combo(m))) return rc;
-  if (!d_particles || !d_all || !d_adam_m || !d_adam_v || !d_x || !d_y || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (!d_particles || !d_x || !d_y) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if ((rc = need_grad(m, n_local))) return rc;
+  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  WgradArgs u{};
+  u.mode = PYZ_UPD_NONE;
+  u.grad = m->grad;
+  u.grad_pstride = m->D;
+  launch_loss_backward(m, d_particles, m->D, n_local, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
+  PYZ_LAUNCH(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, m->scal, m->nonfinite);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
+// phase 2: kernel row(s), repulsion, Adam (SVGD.py:54-68,112-123) on the gradients phase 1 left
+static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                           float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, int sweep, float *d_loss,
+                           hipStream_t st) {
+  int rc;
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (n_local <= 0 || n_local > m->max_p) return pyz_fail(PYZ_E_SHAPE, "particle count %d outside [1, %d] of the plan", n_local, m->max_p);
+  if (!d_particles || !d_all || !d_adam_m || !d_adam_v || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   if (n_total < n_local || row0 < 0 || row0 + n_local > n_total) return pyz_fail(PYZ_E_INVALID, "rows [%d, %d) outside the %d particles", row0, row0 + n_local, n_total);
   if (t < 1) return pyz_fail(PYZ_E_INVALID, "Adam step t must be >= 1");
-  if (!(gamma > 0.0f)) return pyz_fail(PYZ_E_INVALID, "gamma must be positive");
+  const bool median = gamma == PYZ_SVGD_GAMMA_MEDIAN;
+  if (!median && !(gamma > 0.0f)) return pyz_fail(PYZ_E_INVALID, "gamma must be positive (or PYZ_SVGD_GAMMA_MEDIAN)");
   if (sweep != PYZ_SWEEP_GAUSS_SEIDEL && sweep != PYZ_SWEEP_JACOBI) return pyz_fail(PYZ_E_INVALID, "unknown sweep %d", sweep);
   if (sweep == PYZ_SWEEP_GAUSS_SEIDEL && (d_all != d_particles || n_local != n_total))
     return pyz_fail(PYZ_E_INVALID, "the Gauss-Seidel sweep needs the whole particle matrix on this device");
   if (n_total > 1024) return pyz_fail(PYZ_E_INVALID, "more than 1024 particles");
-  if ((rc = need_grad(m, n_local))) return rc;
+  if (!m->grad) return pyz_fail(PYZ_E_INVALID, "pyz_svgd_sweep without a preceding pyz_svgd_gradients");
   const int nblk = cdiv(m->D, PYZ_SVGD_BLOCK_ELEMS);  // one float64 partial per workgroup of k_svgd_dist
   const int rows_at_once = sweep == PYZ_SWEEP_JACOBI ? n_local : 1;
   if ((rc = need_part2(m, (size_t)rows_at_once * nblk * n_total + 8))) return rc;
-  hipStream_t st = as_stream(stream);
-  float *loss = m->scal;  // [n_local]
-  if ((rc = set_ctl(m, 0, batch, lr, t, 0, 0, st))) return rc;
-  // all loss gradients in one particle-batched pass: g_i depends on particle i only (SVGD.py:104-111)
-  {
-    WgradArgs u{};
-    u.mode = PYZ_UPD_NONE;
-    u.grad = m->grad;
-    u.grad_pstride = m->D;
-    launch_loss_backward(m, d_particles, m->D, n_local, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
-  }
-  hipLaunchKernelGGL(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, loss);
+  float *loss = m->scal;  // [n_local], written by phase 1
   SvgdArgs a{};
   a.particles = d_particles;
   a.all = d_all;
@@ -1193,8 +1212,12 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
   a.nblk = nblk;
   const size_t lds = sizeof(double) * (size_t)(5 * n_total);
   const int jgroups = cdiv(n_total, 8);
-  static const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);
-  if (sweep == PYZ_SWEEP_JACOBI && tiles_on && n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles) {
+  const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);  // read per call: tests flip it
+  const bool tile_ok = sweep == PYZ_SWEEP_JACOBI && n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles;
+  if (median && !(tile_ok && n_total % 4 == 0))
+    return pyz_fail(PYZ_E_INVALID, "the median-heuristic bandwidth needs the Jacobi sweep on a snapshot, at most 64 particles, "
+                                   "and particle / local-row counts in multiples of four");
+  if (tile_ok && (tiles_on || median)) {
     // every row from the same snapshot: the particle matrix is read once per pass (k_svgd_*_tile)
     SvgdTileArgs ta{};
     ta.particles = d_particles;
@@ -1210,27 +1233,45 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
     ta.gamma = gamma;
     ta.range = PYZ_SV_E * cdiv(m->D, 256LL * PYZ_SV_E);  // one round of workgroups on the 256 CUs
     ta.nblk = cdiv(m->D, ta.range);
-    const size_t n_part = (size_t)n_local * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
-    if ((rc = need_part2(m, n_part + n_k + n_local + n_diag + 8))) return rc;
+    // the median heuristic (SVGD.py:165-181) needs the squared distances of ALL pairs: the distance pass then covers
+    // every row of the gathered matrix on every rank (the matrix is read once either way)
+    const int dist_rows = median ? n_total : n_local, dist_row0 = median ? 0 : row0;
+    const size_t n_part = (size_t)dist_rows * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
+    const size_t n_dmat = median ? (size_t)n_total * 64 + 8 : 0;
+    if ((rc = need_part2(m, n_part + n_k + n_local + n_diag + n_dmat + 16))) return rc;
     ta.part = full(m)->x.part2;
     ta.kmat = ta.part + n_part;
     ta.ksum = reinterpret_cast<float *>(ta.kmat + n_k);
+    double *after_ksum = ta.kmat + n_k + (n_local + 1) / 2 + 1;
     // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
     // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
     const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
+    SvgdTileArgs td = ta;  // the distance pass
+    td.n_local = dist_rows;
+    td.row0 = dist_row0;
     if (gram_on && mfma_f64_layout_ok(st)) {
-      ta.diag = ta.kmat + n_k + (n_local + 1) / 2 + 1;
-      hipLaunchKernelGGL(k_svgd_gram_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+      td.diag = after_ksum;
+      PYZ_LAUNCH(k_svgd_gram_tile, dim3(td.nblk), dim3(256), 0, st, td);
     } else {
-      ta.diag = nullptr;
-      hipLaunchKernelGGL(k_svgd_dist_tile, dim3(ta.nblk), dim3(256), 0, st, ta);
+      td.diag = nullptr;
+      PYZ_LAUNCH(k_svgd_dist_tile, dim3(td.nblk), dim3(256), 0, st, td);
     }
-    hipLaunchKernelGGL(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta);
-    hipLaunchKernelGGL(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum);
+    ta.diag = td.diag;
+    if (median) {
+      td.dmat = after_ksum + n_diag;           // (M, 64) squared distances, then the bandwidth
+      td.gamma_dev = td.dmat + (size_t)n_total * 64;
+      PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(256), 0, st, td, 1);   // distances only
+      PYZ_LAUNCH(k_svgd_median, dim3(1), dim3(1024), 0, st, td);
+      ta.dmat = td.dmat;
+      ta.gamma_dev = td.gamma_dev;
+    }
+    PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta, 0);
+    PYZ_LAUNCH(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum,
+               (const double *)ta.gamma_dev);
   } else if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
-    hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
+    PYZ_LAUNCH(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
+    PYZ_LAUNCH(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
   } else {
     const int gs_fused = pyz_env_int("PYZ_SVGD_GS_FUSED", 1);  // read per call: tests flip it
     const long long gs_range = 256LL * PYZ_GS_E;
@@ -1259,19 +1300,40 @@ int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_al
         ga.i = i;
         ga.part_in = pp[(i + 2) & 1];   // what launch i - 1 wrote
         ga.part_out = pp[(i + 1) & 1];
-        hipLaunchKernelGGL(k_svgd_gs, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
+        PYZ_LAUNCH(k_svgd_gs, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
       }
     } else {
       for (int i = 0; i < n_local; ++i) {
         a.i_local = i;
-        hipLaunchKernelGGL(k_svgd_dist, dim3(nblk, jgroups, 1), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
+        PYZ_LAUNCH(k_svgd_dist, dim3(nblk, jgroups, 1), dim3(256), 0, st, a);
+        PYZ_LAUNCH(k_svgd_update, dim3(cdiv(m->D, 256), 1), dim3(256), lds, st, a);
       }
     }
   }
-  hipLaunchKernelGGL(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
+  PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
+}
+
+int pyz_svgd_gradients(pyz_mlp *m, const float *d_particles, int n_local, const float *d_x, const void *d_y,
+                       const int32_t *d_row_idx, int batch, void *stream) {
+  return svgd_gradients_impl(m, d_particles, n_local, d_x, d_y, d_row_idx, batch, as_stream(stream));
+}
+
+int pyz_svgd_sweep(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                   float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, int sweep, float *d_loss,
+                   void *stream) {
+  return svgd_sweep_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, sweep, d_loss,
+                         as_stream(stream));
+}
+
+int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                  float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y, const int32_t *d_row_idx,
+                  int batch, float lr, float gamma, int64_t t, int sweep, float *d_loss, void *stream) {
+  const int rc = svgd_gradients_impl(m, d_particles, n_local, d_x, d_y, d_row_idx, batch, as_stream(stream));
+  if (rc) return rc;
+  return svgd_sweep_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, sweep, d_loss,
+                         as_stream(stream));
 }
 
 // ---------------------------------------------------------------- R1
@@ -1289,7 +1351,7 @@ int pyz_predict(pyz_mlp *m, const float *d_weights, int n_samples, const float *
   for (int s0 = 0; s0 < n_samples; s0 += m->max_p) {
     const int S = std::min(m->max_p, n_samples - s0);
     launch_forward(m, d_weights + (long long)s0 * m->D, m->D, S, d_x, nullptr, n, m->ctl, st);
-    hipLaunchKernelGGL(k_predict_finish, dim3(cdiv(n, 256)), dim3(256), 0, st, m->act[m->L - 1],
+    PYZ_LAUNCH(k_predict_finish, dim3(cdiv(n, 256)), dim3(256), 0, st, m->act[m->L - 1],
                        (long long)m->max_batch * C, C, softmax, S, n,
                        d_samples ? d_samples + (long long)s0 * n * C : nullptr, d_mean, s0 > 0 ? 1 : 0,
                        1.0f / (float)n_samples);
@@ -1304,7 +1366,7 @@ int pyz_sample_normal_rows(float *d_out, int64_t n_rows, int64_t row_stride, int
   if (!d_out || !d_loc || !d_scale) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   if (n_rows <= 0 || n_rows > 65535 || len <= 0 || col0 < 0 || col0 + len > row_stride)
     return pyz_fail(PYZ_E_INVALID, "bad draw count / column range");
-  hipLaunchKernelGGL(k_sample_normal_rows, dim3(cdiv(cdiv(len, 4), 256), (unsigned)n_rows), dim3(256), 0, as_stream(stream), d_out,
+  PYZ_LAUNCH(k_sample_normal_rows, dim3(cdiv(cdiv(len, 4), 256), (unsigned)n_rows), dim3(256), 0, as_stream(stream), d_out,
                      (long long)row_stride, (long long)col0, (long long)len, d_loc, d_scale, seed, stream_id, first_draw);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -1313,7 +1375,7 @@ int pyz_sample_normal_rows(float *d_out, int64_t n_rows, int64_t row_stride, int
 int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step, float mean, float std,
                     void *stream) {
   if (!d_out || n <= 0) return pyz_fail(PYZ_E_INVALID, "bad output buffer");
-  hipLaunchKernelGGL(k_fill_normal, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, as_stream(stream), d_out, (long long)n,
+  PYZ_LAUNCH(k_fill_normal, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, as_stream(stream), d_out, (long long)n,
                      seed, stream_id, step, mean, std);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
@@ -1375,11 +1437,103 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
   return PYZ_OK;
 }
 
+// ---------------------------------------------------------------- per-launch timing
+int pyz_probe_begin(int max_launches) {
+  if (max_launches < 1 || max_launches > (1 << 20)) return pyz_fail(PYZ_E_INVALID, "max_launches outside [1, 2^20]");
+  PyzProbe &p = pyz_probe();
+  if (p.on) return pyz_fail(PYZ_E_INVALID, "a probe is already open on this thread");
+  while ((int)p.ev.size() < 2 * max_launches) {
+    hipEvent_t e = nullptr;
+    PYZ_HIP(hipEventCreate(&e));
+    p.ev.push_back(e);
+  }
+  p.name.assign((size_t)max_launches, nullptr);
+  p.cap = max_launches;
+  p.n = 0;
+  p.on = true;
+  return PYZ_OK;
+}
+
+int pyz_probe_end(void *stream, float *h_us, char *h_names, int name_stride, int *h_n) {
+  PyzProbe &p = pyz_probe();
+  if (!p.on) return pyz_fail(PYZ_E_INVALID, "no probe open on this thread");
+  p.on = false;
+  if (!h_us || !h_n) return pyz_fail(PYZ_E_INVALID, "null pointer");
+  PYZ_HIP(hipStreamSynchronize(as_stream(stream)));
+  for (int i = 0; i < p.n; ++i) {
+    float ms = 0.0f;
+    PYZ_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+    h_us[i] = ms * 1e3f;
+    if (h_names && name_stride > 1) {
+      const char *nm = p.name[i] ? p.name[i] : "";
+      const bool wrapped = nm[0] == '(';  // "(k_head_rows<4, 12>)": the launch site wraps template kernels in parentheses
+      char *dst = h_names + (size_t)i * name_stride;
+      std::snprintf(dst, (size_t)name_stride, "%s", nm + (wrapped ? 1 : 0));
+      const size_t len = std::strlen(dst);
+      if (wrapped && len > 0 && dst[len - 1] == ')') dst[len - 1] = '\0';
+    }
+  }
+  *h_n = p.n;
+  return PYZ_OK;
+}
+
+int pyz_last_run_info(const pyz_mlp *m, int32_t *h_graph_steps, int32_t *h_eager_steps, int32_t *h_graph_launches) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (h_graph_steps) *h_graph_steps = m->run_graph_steps;
+  if (h_eager_steps) *h_eager_steps = m->run_eager_steps;
+  if (h_graph_launches) *h_graph_launches = m->run_graph_launches;
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- non-finite sentinel
+int pyz_check_finite(pyz_mlp *m, void *stream) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  hipStream_t st = as_stream(stream);
+  int n = 0;
+  PYZ_HIP(hipMemcpyAsync(&n, m->nonfinite, sizeof n, hipMemcpyDeviceToHost, st));
+  PYZ_HIP(hipMemsetAsync(m->nonfinite, 0, sizeof n, st));
+  PYZ_HIP(hipStreamSynchronize(st));
+  if (n > 0) return pyz_fail(PYZ_E_NAN, "%d step(s) since the last check produced a NaN / Inf loss", n);
+  return PYZ_OK;
+}
+
+// ---------------------------------------------------------------- memory of callers without a device allocator
+int pyz_malloc(size_t bytes, void **d_out) {
+  if (!d_out || bytes == 0) return pyz_fail(PYZ_E_INVALID, "bad allocation request");
+  *d_out = nullptr;
+  PYZ_HIP(hipMalloc(d_out, bytes));
+  return PYZ_OK;
+}
+
+int pyz_free(void *d_ptr) {
+  if (d_ptr) PYZ_HIP(hipFree(d_ptr));
+  return PYZ_OK;
+}
+
+int pyz_upload(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+  if (!d_dst || !h_src) return pyz_fail(PYZ_E_INVALID, "null pointer");
+  PYZ_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  PYZ_HIP(hipStreamSynchronize(as_stream(stream)));  // the host buffer is the caller's again on return
+  return PYZ_OK;
+}
+
+int pyz_download(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+  if (!h_dst || !d_src) return pyz_fail(PYZ_E_INVALID, "null pointer");
+  PYZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  PYZ_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PYZ_OK;
+}
+
+int pyz_sync(void *stream) {
+  PYZ_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PYZ_OK;
+}
+
 int pyz_debug_mfma_f64_layout(int32_t *h_out512) {
   if (!h_out512) return pyz_fail(PYZ_E_INVALID, "null pointer");
   int *d = nullptr;
   PYZ_HIP(hipMalloc((void **)&d, 512 * sizeof(int)));
-  hipLaunchKernelGGL(k_probe_mfma_f64, dim3(1), dim3(64), 0, nullptr, d);
+  PYZ_LAUNCH(k_probe_mfma_f64, dim3(1), dim3(64), 0, nullptr, d);
   const hipError_t e = hipMemcpy(h_out512, d, 512 * sizeof(int), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   PYZ_HIP(e);

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -112,7 +113,34 @@ inline int pyz_fail(int code, const char *fmt, ...) {
                       __FILE__, __LINE__);                                                    \
   } while (0)
 
+// ---------------------------------------------------------------- per-launch timing (measurement only)
+// Between pyz_probe_begin and pyz_probe_end every kernel launch of the calling thread goes out through
+// hipExtLaunchKernelGGL with a start and a stop event of its own: the pair reads the dispatch's begin / end
+// timestamps (what rocprofv3 --kernel-trace reports as the kernel's duration), with no extra packet between
+// two kernels of the pipeline.  Off (the normal state): a plain launch.
+struct PyzProbe {
+  std::vector<hipEvent_t> ev;       // 2 per launch
+  std::vector<const char *> name;   // the kernel expression of the launch site
+  int n = 0, cap = 0;
+  bool on = false;
+};
+inline PyzProbe &pyz_probe() {
+  static thread_local PyzProbe p;
+  return p;
+}
+#define PYZ_LAUNCH(kern, grid, block, lds, st, ...)                                                              \
+  do {                                                                                                           \
+    PyzProbe &pp_ = pyz_probe();                                                                                 \
+    if (pp_.on && pp_.n < pp_.cap) {                                                                             \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, pp_.ev[2 * pp_.n], pp_.ev[2 * pp_.n + 1], 0, __VA_ARGS__); \
+      pp_.name[pp_.n++] = #kern;                                                                                 \
+    } else {                                                                                                     \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                               \
+    }                                                                                                            \
+  } while (0)
+
 // ---------------------------------------------------------------- the plan
+#define PYZ_GRAPH_CHUNKS 8  // captured step graphs of G, then 2^k < G, ..., 2, 1 steps
 struct pyz_mlp {
   int L = 0;
   int dims[PYZ_MAX_LAYERS + 1] = {0};
@@ -131,7 +159,6 @@ struct pyz_mlp {
   float *qsave = nullptr;                    // (P, D) HMC snapshot
   double *part = nullptr;                    // reduction partials
   int part_len = 0;
-  hipEvent_t *probe = nullptr;               // optional: 4 events recorded around the kernels of one fused step
   int cur_nblk = 0;                          // number of loss partials the last loss launch wrote per particle
   float *scal = nullptr;                     // small device scalars
   StepCtl *ctl = nullptr;                    // device StepCtl
@@ -141,7 +168,12 @@ struct pyz_mlp {
   float *tab_lr = nullptr;
   int tab_cap = 0;
   float *h_pinned = nullptr;                 // pinned host staging
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  // device-resident runs: one captured graph per chunk length (everything baked into them goes into graph_key)
+  hipGraph_t graph[PYZ_GRAPH_CHUNKS] = {nullptr};
+  hipGraphExec_t graph_exec[PYZ_GRAPH_CHUNKS] = {nullptr};
+  int graph_len[PYZ_GRAPH_CHUNKS] = {0};
   unsigned long long graph_key = 0;
+  // what the last pyz_*_run call did: steps inside replayed graphs, eager steps, graph launches
+  int run_graph_steps = 0, run_eager_steps = 0, run_graph_launches = 0;
+  int *nonfinite = nullptr;                  // device counter: steps whose loss was NaN / Inf (pyz_check_finite)
 };

@@ -465,6 +465,7 @@ struct WgradArgs {
   const int32_t *tab_bs;
   const float *tab_lr;
   long long row_stride;
+  int *nonfinite;             // device counter of steps with a NaN / Inf loss (may be nullptr)
 };
 
 // ---------------------------------------------------------------- the optimizer updates (shared by the
@@ -547,6 +548,7 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
     if (l == 0) {
       float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
       lo[0] = (float)(v / (double)batch);
+      pyz_note_loss(g.nonfinite, lo[0]);
       if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
     }
   }
@@ -555,6 +557,7 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
     if (l == 0) {
       const float loss = (float)(v / (double)batch), kl = (float)k;
       g.cost[0] = loss + g.alpha * kl;
+      pyz_note_loss(g.nonfinite, g.cost[0]);
       g.cost[1] = loss;
       g.cost[2] = kl;
     }

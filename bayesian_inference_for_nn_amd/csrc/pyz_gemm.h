@@ -594,22 +594,22 @@ static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hip
     const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
     const long long tl = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT));
     const dim3 grid(pyz_pad8(tl, P), P), block(256);
-    if (NT == 2) hipLaunchKernelGGL(k_dense_fwd_lds<2>, grid, block, 0, st, g);
-    else if (NT == 4) hipLaunchKernelGGL(k_dense_fwd_lds<4>, grid, block, 0, st, g);
-    else hipLaunchKernelGGL(k_dense_fwd_lds<7>, grid, block, 0, st, g);
+    if (NT == 2) PYZ_LAUNCH(k_dense_fwd_lds<2>, grid, block, 0, st, g);
+    else if (NT == 4) PYZ_LAUNCH(k_dense_fwd_lds<4>, grid, block, 0, st, g);
+    else PYZ_LAUNCH(k_dense_fwd_lds<7>, grid, block, 0, st, g);
     return;
   }
-  hipLaunchKernelGGL(k_dense_fwd, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+  PYZ_LAUNCH(k_dense_fwd, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }
 
 static inline void pyz_launch_bwd_data(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
   const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.K + 31) / 32);
   const int S = pyz_pick_waves(tiles * P, (g.N + 1) / 2);
-  hipLaunchKernelGGL(k_dense_bwd_data, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+  PYZ_LAUNCH(k_dense_bwd_data, dim3(pyz_pad8(tiles, P), P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }
 
 static inline void pyz_launch_bwd_weight(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
   const long long tiles = (long long)((g.K + 1 + 31) / 32) * ((g.N + 31) / 32);
   const int S = pyz_pick_waves(tiles * P, (grid_batch + 1) / 2);
-  hipLaunchKernelGGL(k_dense_bwd_weight, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
+  PYZ_LAUNCH(k_dense_bwd_weight, dim3((unsigned)tiles, P), dim3(64 * S), S > 1 ? S * 4096 : 0, st, g);
 }

@@ -54,6 +54,12 @@ __device__ __forceinline__ float pyz_softplus(float x) {
 }
 __device__ __forceinline__ float pyz_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Non-finite sentinel: every kernel that finalises a step's loss counts the steps whose loss
+// is NaN / Inf in a device counter the host reads through pyz_check_finite.
+__device__ __forceinline__ void pyz_note_loss(int *counter, const float v) {
+  if (counter && !(fabsf(v) <= 3.0e38f)) atomicAdd(counter, 1);
+}
+
 // ---------------------------------------------------------------- step control
 __global__ void k_set_ctl(StepCtl *ctl, int batch, float lr, long long n, long long row_off, int i, int slot0) {
   ctl->batch = batch;
@@ -146,29 +152,35 @@ __global__ void k_loss_mse(LossArgs g) {
 }
 
 // loss[p] = (sum of the row-loss partials) / batch
-__global__ void k_loss_finalize(const double *part, int nblk, const StepCtl *ctl, float *loss) {
+__global__ void k_loss_finalize(const double *part, int nblk, const StepCtl *ctl, float *loss, int *nonfinite) {
   const int p = blockIdx.x;   // one 64-lane wave per particle
   const double tot = pyz_sum_partials(part + p * nblk, nblk);
-  if (threadIdx.x == 0) loss[p] = (float)(tot / (double)ctl->batch);
+  if (threadIdx.x == 0) {
+    loss[p] = (float)(tot / (double)ctl->batch);
+    pyz_note_loss(nonfinite, loss[p]);
+  }
 }
 
 // ---------------------------------------------------------------- SGD / SGLD
 // SGD.step update (SGD.py:66-69): theta -= lr * grad.
 __global__ void k_sgd_update(float *theta, const float *grad, long long D, const StepCtl *ctl, const double *part,
-                             int nblk, float *loss) {
+                             int nblk, float *loss, int *nonfinite) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const float lr = ctl->lr;
   if (e < D) theta[e] = theta[e] - lr * grad[e];
   if (blockIdx.x == 0 && threadIdx.x < 64) {   // first wave of the launch
     const double tot = pyz_sum_partials(part, nblk);
-    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)ctl->batch);
+    if (threadIdx.x == 0) {
+      loss[0] = (float)(tot / (double)ctl->batch);
+      pyz_note_loss(nonfinite, loss[0]);
+    }
   }
 }
 
 // SWAG.step update for nets the fused path does not take (SWAG.py:61-92): SGD update, then (when
 // `update`) the running moments with count n and one deviation row.
 __global__ void k_swag_update(float *theta, float *mean, float *sq_mean, float *dev_row, const float *grad, long long D,
-                              int update, const StepCtl *ctl, const double *part, int nblk, float *loss) {
+                              int update, const StepCtl *ctl, const double *part, int nblk, float *loss, int *nonfinite) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const float lr = ctl->lr;
   if (e < D) {
@@ -184,7 +196,10 @@ __global__ void k_swag_update(float *theta, float *mean, float *sq_mean, float *
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     const double tot = pyz_sum_partials(part, nblk);
-    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)ctl->batch);
+    if (threadIdx.x == 0) {
+      loss[0] = (float)(tot / (double)ctl->batch);
+      pyz_note_loss(nonfinite, loss[0]);
+    }
   }
 }
 
@@ -207,6 +222,7 @@ struct SgldArgs {
   int nblk;
   float *loss;              // eager: slot 0; run: indexed by ctl->i
   int loss_indexed;
+  int *nonfinite;
 };
 
 __global__ void k_sgld_update(SgldArgs g) {
@@ -241,6 +257,7 @@ __global__ void k_sgld_update(SgldArgs g) {
     if (threadIdx.x == 0) {
       float *lo = g.loss + (g.loss_indexed ? g.ctl->slot0 + g.ctl->i : 0);
       lo[0] = (float)(tot / (double)g.ctl->batch);
+      pyz_note_loss(g.nonfinite, lo[0]);
       if (g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
     }
   }
@@ -650,6 +667,9 @@ struct SvgdTileArgs {
   double *kmat;            // (n_local, 64) kernel values (0 past M)
   float *ksum;             // (n_local)
   double *diag;            // Gram form only: (nblk, 64) partial squared norms of all particles; else nullptr
+  // median-heuristic bandwidth (SVGD.py:165-181) only: the squared distances of ALL pairs and the bandwidth they give
+  double *dmat;            // (M, 64) squared distances (0 past M), or nullptr
+  double *gamma_dev;       // [1] gamma = 1 / (2 h^2) = log(M + 1) / median(d), or nullptr: the fixed `gamma`
 };
 
 __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
@@ -849,40 +869,87 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
   if (t < 64) g.diag[(long long)blockIdx.x * 64 + t] = gbuf[t * 64 + t];
 }
 
-__global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g) {
+// dist_only != 0: the squared distances of the row go to g.dmat and nothing else happens (first half of the
+// median-heuristic path); with g.dmat set and dist_only == 0 the distances are read from there.
+__global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
   __shared__ double sl[4][64], sg[4][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const double *pp = g.part + (long long)il * g.nblk * 64 + j;
-  double s = 0.0, sn = 0.0;
-  for (int b0 = q; b0 < g.nblk; b0 += 32) {
-    double v[8], n[8];
+  double d;
+  if (g.dmat && !dist_only) {
+    if (q != 0) return;
+    d = g.dmat[(g.row0 + il) * 64 + j];
+  } else {
+    const double *pp = g.part + (long long)il * g.nblk * 64 + j;
+    double s = 0.0, sn = 0.0;
+    for (int b0 = q; b0 < g.nblk; b0 += 32) {
+      double v[8], n[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
-      n[u] = (g.diag && b0 + 4 * u < g.nblk) ? g.diag[(long long)(b0 + 4 * u) * 64 + j] : 0.0;
+      for (int u = 0; u < 8; ++u) {
+        v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
+        n[u] = (g.diag && b0 + 4 * u < g.nblk) ? g.diag[(long long)(b0 + 4 * u) * 64 + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += v[u];
+        sn += n[u];
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      s += v[u];
-      sn += n[u];
+    sl[q][j] = s;
+    sg[q][j] = sn;
+    __syncthreads();
+    if (q != 0) return;
+    d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
+    if (g.diag) {  // Gram form: the partials are inner products; d_ij = |x_i|^2 + |x_j|^2 - 2 x_i . x_j (d_ii = 0 exactly)
+      const int i = g.row0 + il;
+      const double nj = (sg[0][j] + sg[1][j]) + (sg[2][j] + sg[3][j]);
+      const double ni = (sg[0][i] + sg[1][i]) + (sg[2][i] + sg[3][i]);
+      d = (j == i) ? 0.0 : fmax((ni + nj) - 2.0 * d, 0.0);
+    }
+    if (dist_only) {
+      g.dmat[(g.row0 + il) * 64 + j] = j < g.M ? d : 0.0;
+      return;
     }
   }
-  sl[q][j] = s;
-  sg[q][j] = sn;
-  __syncthreads();
-  if (q != 0) return;
-  double d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
-  if (g.diag) {  // Gram form: the partials are inner products; d_ij = |x_i|^2 + |x_j|^2 - 2 x_i . x_j (d_ii = 0 exactly)
-    const int i = g.row0 + il;
-    const double nj = (sg[0][j] + sg[1][j]) + (sg[2][j] + sg[3][j]);
-    const double ni = (sg[0][i] + sg[1][i]) + (sg[2][i] + sg[3][i]);
-    d = (j == i) ? 0.0 : fmax((ni + nj) - 2.0 * d, 0.0);
-  }
-  const double k = j < g.M ? exp(-(double)g.gamma * d) : 0.0;
+  const double gam = g.gamma_dev ? g.gamma_dev[0] : (double)g.gamma;
+  const double k = j < g.M ? exp(-gam * d) : 0.0;
   g.kmat[il * 64 + j] = k;
   float ks = 0.0f;
   for (int u = 0; u < g.M; ++u) ks += (float)__shfl(k, u, 64);
   if (j == 0) g.ksum[il] = ks;
+}
+
+// The median heuristic of SVGD.baseline__kernel (SVGD.py:165-181, dead code in the reference; opt-in here):
+//   h = sqrt(0.5 median(sqdist) / log(M + 1)),  K = exp(-sqdist / (2 h^2))   =>   gamma = log(M + 1) / median(sqdist),
+// the median over ALL M^2 entries of the squared-distance matrix (numpy.median: the mean of the two middle
+// values for an even count).  One workgroup of 1024 threads sorts the M^2 <= 4096 values in LDS (bitonic
+// network on the next power of two, padded with +inf) -- a fixed sequence of compare-exchanges: bitwise
+// reproducible.  The repulsion term (-K X + X rowsum K) / h^2 is 2 gamma sum_j K_ij (x_i - x_j) with this gamma.
+__global__ void __launch_bounds__(1024) k_svgd_median(SvgdTileArgs g) {
+  __shared__ double v[4096];
+  const int t = threadIdx.x, M = g.M, n = M * M;
+  int n2 = 2;
+  while (n2 < n) n2 *= 2;
+  for (int e = t; e < n2; e += 1024) v[e] = e < n ? g.dmat[(e / M) * 64 + (e % M)] : __builtin_inf();
+  __syncthreads();
+  for (int k = 2; k <= n2; k *= 2)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = t; e < n2; e += 1024) {
+        const int p = e ^ j;
+        if (p > e) {
+          const double a = v[e], b = v[p];
+          const bool up = (e & k) == 0;
+          if ((a > b) == up) {
+            v[e] = b;
+            v[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (t == 0) {
+    const double med = (n & 1) ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+    g.gamma_dev[0] = log((double)M + 1.0) / med;
+  }
 }
 
 // phi_i and the legacy Adam step (the arithmetic of k_svgd_update) for every local row, one element per thread.
@@ -890,7 +957,8 @@ __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g) {
 // arguments, so the compiler may use s_load) and feed the float64 FMAs as SGPR operands; reading them
 // from LDS cost one 512-byte broadcast per (row, j) and made the kernel LDS-bound (222 us).
 __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const double *__restrict__ kmat,
-                                                          const float *__restrict__ ksum) {
+                                                          const float *__restrict__ ksum,
+                                                          const double *__restrict__ gamma_dev) {
   const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
   if (d >= g.D) return;
   // x_j[d] of every particle: all 64 loads are issued before the first use (rows past M repeat the last one
@@ -917,7 +985,7 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
       k4[j & 3] += kr[j];          // (wave-uniform: scalar-side work)
     }
     double rep = xid * ((k4[0] + k4[1]) + (k4[2] + k4[3])) - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
-    rep *= 2.0 * (double)g.gamma;
+    rep *= 2.0 * (gamma_dev ? gamma_dev[0] : (double)g.gamma);
     const long long o = (long long)il * g.D + d;
     const float phi = (ksum[il] * g.grad[o] + (float)rep) / (float)g.M;
     float m = g.adam_m[o], v = g.adam_v[o];
@@ -1039,7 +1107,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   for (int j = 0; j < PYZ_GS_AHEAD; ++j) load_row(j);
   PYZ_GS_STAMP(1);
   // -- the K row of particle i, while the first rows are on their way (its partials were requested first)
-  float kf[64];
+  double kd[64];
   float ksum = 0.0f;
   if (i >= 0) {
     {  // squared distances of row i: the partials of a row are summed by 8 threads (stride-8 slices), fixed order
@@ -1064,14 +1132,14 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     // latency 64 times); rows past M hold 0
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-      kf[j] = (float)sd[j];
-      ksum += kf[j];   // (+0.0f past M: the sum over j < M, same order)
+      kd[j] = sd[j];
+      ksum += (float)kd[j];   // (+0.0f past M: the sum over j < M, same order)
     }
   }
   PYZ_GS_STAMP(3);
-  float rep[PYZ_GS_E];
+  double rep[PYZ_GS_E];
 #pragma unroll
-  for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0f;
+  for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
 #pragma unroll
   for (int j = 0; j < 64; ++j) {
     if (j + PYZ_GS_AHEAD < 64) load_row(j + PYZ_GS_AHEAD);
@@ -1083,10 +1151,10 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     }
     asm volatile("" : "+v"(a)::"memory");
     acc[j] = a;
-    if (i >= 0) {  // repulsion term of this row, in float32 (see below)
+    if (i >= 0) {  // repulsion term of this row, in float64 like the kernel values (see below)
 #pragma unroll
       for (int q = 0; q < PYZ_GS_E; ++q) {
-        rep[q] = fmaf(kf[j], xi[q] - x[j][q], rep[q]);
+        rep[q] = fma(kd[j], (double)xi[q] - (double)x[j][q], rep[q]);
         asm volatile("" : "+v"(rep[q]));
       }
     }
@@ -1094,12 +1162,13 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   PYZ_GS_STAMP(4);
   double acc_i = 0.0;
   if (i >= 0) {
-    // (the repulsion sum was taken in float32 as the rows arrived: phi is a float32 quantity and the 64 terms
-    // K_ij (x_i - x_j) carry no cancellation that float32 products would lose against it; row i -- difference
-    // 0 -- and underflowed rows add exactly 0)
+    // (the repulsion sum was taken in float64 as the rows arrived -- the reference differentiates the float64
+    // kernel sum and casts the result once, SVGD.py:59-63 -- with k_svgd_update's arithmetic: where the 64 terms
+    // K_ij (x_i - x_j) cancel, a float32 sum loses the SIGN of phi, and Adam's first steps move by lr sign(phi);
+    // row i -- difference 0 -- and underflowed rows add exactly 0)
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
-      const float phi = (ksum * gi[q] + rep[q] * (2.0f * g.gamma)) / (float)M;
+      const float phi = (ksum * gi[q] + (float)(rep[q] * (2.0 * (double)g.gamma))) / (float)M;
       const float m = am[q] + (phi - am[q]) * (1.0f - 0.9f);
       const float v = av[q] + (phi * phi - av[q]) * (1.0f - 0.999f);
       const float xn = xi[q] - g.lr_t * m / (sqrtf(v) + 1e-7f);

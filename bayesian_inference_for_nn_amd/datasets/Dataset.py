@@ -101,12 +101,19 @@ class Dataset:
         if isinstance(dataset, str) and not dataset.endswith(".csv"):
             if dataset == "mnist":
                 # tfds.load('mnist') is a network fetch (Dataset.py:65): MNIST-shaped synthetic stand-in
+                import warnings
                 from .. import synth
+                warnings.warn("Dataset('mnist'): tensorflow_datasets needs the network; substituting SYNTHETIC MNIST-shaped "
+                              "data (uniform pixels, random labels) -- accuracies on it are meaningless", RuntimeWarning,
+                              stacklevel=2)
                 x, y = synth.mnist_like(60_000)
                 dataset = (x.reshape(-1, 28, 28), y)
             else:
                 raise ValueError("Unsupported dataset format (named tfds data sets need the network)")
         x, y = _to_arrays(dataset, target_dim)
+        from .. import parallel
+        if parallel.world_info()[1] > 1:        # one split for all ranks (sharded SVGD shares batches and validation rows)
+            seed = parallel.shared_seed(seed)
         perm = np.random.default_rng(seed).permutation(len(x))       # Dataset.py:114
         x, y = x[perm], y[perm]
         self.size = len(x)

@@ -46,6 +46,15 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _gamma(gamma) -> float:
+    """Fixed RBF bandwidth, or None / "median" for the median heuristic (PYZ_SVGD_GAMMA_MEDIAN)."""
+    if gamma is None or gamma == "median":
+        return _lib.GAMMA_MEDIAN
+    if not float(gamma) > 0.0:
+        raise ValueError("gamma must be positive, or None / 'median' for the median heuristic")
+    return float(gamma)
+
+
 def _f32(t: torch.Tensor, shape=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError(f"{name} must be a CUDA(HIP) torch tensor")
@@ -221,24 +230,22 @@ class MLPPlan:
                                     ptr(x), ptr(y), ptr(row_idx), bs, lr, n_steps, int(n0), int(slot0), ptr(losses_out),
                                     1 if use_graph else 0, _stream()))
 
-    def sgld_profile(self, theta, mean, sq_mean, x, y, row_idx, batch_sizes, lrs, n0, seed, losses_out, slot0=0):
-        """n eager steps with HIP events around each kernel; returns average microseconds of
-        (forward, head, weight gradient + update) inside the pipeline."""
-        n_steps = len(batch_sizes)
-        assert len(lrs) == n_steps and 0 < n_steps <= 4096
-        for t, nm in ((theta, "theta"), (mean, "mean"), (sq_mean, "sq_mean")):
-            _f32(t, (self.D,), nm)
-        self._check_xy(x, y, row_idx, 1)
-        if slot0 < 0 or row_idx.numel() < (slot0 + n_steps) * self.max_batch or losses_out.numel() < slot0 + n_steps:
-            raise ValueError("row_idx / losses_out too small")
-        if any(int(b) < 1 or int(b) > self.max_batch for b in batch_sizes):
-            raise ValueError("batch size outside the plan")
-        bs = (C.c_int32 * n_steps)(*[int(b) for b in batch_sizes])
-        lr = (C.c_float * n_steps)(*[float(v) for v in lrs])
-        out = (C.c_float * 3)()
-        check(self.lib.pyz_sgld_profile(self.h, ptr(theta), ptr(mean), ptr(sq_mean), ptr(x), ptr(y), ptr(row_idx), bs, lr,
-                                        n_steps, int(n0), int(slot0), int(seed), ptr(losses_out), out, _stream()))
-        return [float(v) for v in out]
+    def last_run_path(self):
+        """("graph" | "eager" | "mixed", steps) of the last sgld_run / sgd_run / swag_run call on this plan."""
+        g, e, n = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.pyz_last_run_info(self.h, C.byref(g), C.byref(e), C.byref(n)))
+        kind = "graph" if e.value == 0 else ("eager" if g.value == 0 else "mixed")
+        return kind, g.value + e.value
+
+    def last_run_graph_launches(self) -> int:
+        n = C.c_int32()
+        check(self.lib.pyz_last_run_info(self.h, None, None, C.byref(n)))
+        return n.value
+
+    def check_finite(self):
+        """Synchronises the current stream; raises PyzError (code E_NAN) if a step since the last check produced a
+        NaN / Inf loss."""
+        check(self.lib.pyz_check_finite(self.h, _stream()))
 
     # ------------------------------------------------------------------ B2-B4
     def bbb_step(self, mu, rho, w, x, y, lr, alpha, prior_mean, prior_rho, step, seed, cost_out, batch=None,
@@ -292,7 +299,27 @@ class MLPPlan:
         self._check_xy(x, y, row_idx, batch)
         check(self.lib.pyz_svgd_step(self.h, ptr(particles), n_local, ptr(all_particles), n_total, int(row0),
                                      ptr(adam_m), ptr(adam_v), ptr(x), ptr(y), ptr(row_idx), batch, float(lr),
-                                     float(gamma), int(t), SWEEP[sweep], ptr(loss_out), _stream()))
+                                     _gamma(gamma), int(t), SWEEP[sweep], ptr(loss_out), _stream()))
+
+    def svgd_gradients(self, particles, x, y, batch=None, row_idx=None):
+        """Phase 1 of svgd_step: the loss gradients of the local particles (kept inside the plan)."""
+        _f32(particles, name="particles")
+        assert particles.dim() == 2 and particles.shape[1] == self.D
+        batch = int(batch if batch is not None else (row_idx.numel() if row_idx is not None else x.shape[0]))
+        self._check_xy(x, y, row_idx, batch)
+        check(self.lib.pyz_svgd_gradients(self.h, ptr(particles), particles.shape[0], ptr(x), ptr(y), ptr(row_idx), batch,
+                                          _stream()))
+
+    def svgd_sweep(self, particles, all_particles, row0, adam_m, adam_v, lr, gamma, t, loss_out, sweep="gauss_seidel"):
+        """Phase 2: kernel rows, repulsion and Adam on the gradients svgd_gradients left; first reader of all_particles."""
+        _f32(particles, name="particles")
+        _f32(all_particles, name="all_particles")
+        n_local, n_total = particles.shape[0], all_particles.shape[0]
+        assert particles.shape[1] == self.D and all_particles.shape[1] == self.D
+        _f32(adam_m, (n_local, self.D), "adam_m")
+        _f32(adam_v, (n_local, self.D), "adam_v")
+        check(self.lib.pyz_svgd_sweep(self.h, ptr(particles), n_local, ptr(all_particles), n_total, int(row0), ptr(adam_m),
+                                      ptr(adam_v), float(lr), _gamma(gamma), int(t), SWEEP[sweep], ptr(loss_out), _stream()))
 
     # ------------------------------------------------------------------ R1
     def predict(self, weights, x, want_samples=True):
@@ -307,6 +334,38 @@ class MLPPlan:
         mean = torch.empty((n, C_out), dtype=torch.float32, device=self.device)
         check(self.lib.pyz_predict(self.h, ptr(weights), S, ptr(x), n, ptr(samples), ptr(mean), _stream()))
         return samples, mean
+
+
+class KernelProbe:
+    """with KernelProbe(max_launches) as kp: ...launch steps...  -> kp.launches = [(kernel expression, microseconds)]
+    in launch order: each kernel's own begin / end timestamps (measurement only; runs launch eagerly inside)."""
+
+    def __init__(self, max_launches: int = 4096):
+        self.max = int(max_launches)
+        self.launches = []
+
+    def __enter__(self):
+        check(_lib.load().pyz_probe_begin(self.max))
+        return self
+
+    def __exit__(self, *exc):
+        us = (C.c_float * self.max)()
+        names = C.create_string_buffer(self.max * 64)
+        n = C.c_int()
+        rc = _lib.load().pyz_probe_end(_stream(), us, names, 64, C.byref(n))
+        if exc[0] is None:
+            check(rc)
+            raw = names.raw
+            self.launches = [(raw[64 * i:64 * i + 64].split(b"\0", 1)[0].decode(), float(us[i])) for i in range(n.value)]
+        return False
+
+    def by_kernel(self):
+        """{kernel expression: (launch count, mean microseconds)}"""
+        acc = {}
+        for name, v in self.launches:
+            c, t = acc.get(name, (0, 0.0))
+            acc[name] = (c + 1, t + v)
+        return {k: (c, t / c) for k, (c, t) in acc.items()}
 
 
 def fill_normal(out: torch.Tensor, seed: int, stream_id: int, step: int, mean: float = 0.0, std: float = 1.0):

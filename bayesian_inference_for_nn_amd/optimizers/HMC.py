@@ -31,6 +31,7 @@ class HMC(Optimizer):
         self._L = self._hyperparameters.L
         self._epsilon = self._hyperparameters.epsilon
         self._n_chains = int(kwargs.get("n_chains", 1))
+        self._merge_ranks = bool(kwargs.get("merge_ranks", True))
         self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_chains, full_batch=True)
         self._model = self._net
         self._samples = []
@@ -164,6 +165,10 @@ class HMC(Optimizer):
         for c in range(self._n_chains):
             samples += [s.cpu().numpy() for s in self._chain_samples[c]]
             freqs += list(self._chain_freq[c])
+        if self._world > 1 and self._merge_ranks:
+            # independent chains on every rank: one Sampled posterior over all of them (every rank gets it)
+            from .. import parallel
+            samples, freqs = parallel.merge_sampled_chains(samples, freqs)
         distribution = Sampled(samples, freqs)
         posterior_model = BayesianModel(self._model_config)
         posterior_model.apply_distribution(distribution, 0, len(self._net.layers) - 1)

@@ -143,12 +143,17 @@ class Optimizer(ABC):
         print()
 
     # ------------------------------------------------------------------ device-resident data
-    def _setup_backend(self, seed=None, max_particles=1, full_batch=False):
-        """Builds the model, the kernel plan and the device copy of the training split."""
+    def _setup_backend(self, seed=None, max_particles=1, full_batch=False, chain_per_rank=True):
+        """Builds the model, the kernel plan and the device copy of the training split.
+        Several ranks (one process per GPU): every rank starts from the SAME base seed (the given one, else rank
+        0's entropy); independent chains (chain_per_rank) use base + rank, sharded SVGD the base itself -- its
+        ranks must draw one batch permutation and one particle initialisation."""
         import torch
+        from .. import parallel
         from ..engine import MLPPlan, MLPSpec
         from ..nn.model import model_from_json
-        self._seed = int(seed) if seed is not None else int.from_bytes(os.urandom(6), "little")
+        self._rank, self._world = parallel.world_info()
+        self._seed = parallel.shared_seed(seed) + (self._rank if chain_per_rank else 0)
         self._rng = np.random.default_rng(self._seed)
         self._net = model_from_json(self._model_config)
         self._net.reset_glorot(self._rng)

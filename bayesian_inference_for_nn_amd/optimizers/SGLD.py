@@ -36,6 +36,7 @@ class SGLD(Optimizer):
         self._lr_lower = self._hyperparameters.lr_lower
         self._lr_gamma = self._hyperparameters.lr_gamma
         self._setup_backend(seed=kwargs.get("seed"))
+        self._merge_ranks = bool(kwargs.get("merge_ranks", True))
         self._base_model = self._net
         self._dataset_setup()
         self._theta = torch.as_tensor(self._net.weights_flat.copy()).cuda()
@@ -85,8 +86,13 @@ class SGLD(Optimizer):
 
     def result(self) -> BayesianModel:
         model = BayesianModel(self._model_config)
-        mean = self._mean_dev.cpu().numpy()
-        sq_mean = self._sq_mean_dev.cpu().numpy()
+        mean_dev, sq_dev = self._mean_dev, self._sq_mean_dev
+        if self._world > 1 and self._merge_ranks:
+            # one chain per rank (no data-path collective): the running moments pool with the chains' step counts
+            from .. import parallel
+            mean_dev, sq_dev, self.pooled_steps = parallel.merge_moment_chains(mean_dev, sq_dev, self._n)
+        mean = mean_dev.cpu().numpy()
+        sq_mean = sq_dev.cpu().numpy()
         for sl, layer_idx in zip(self._spec.layer_slices(), self._weight_layers_indices):
             # Normal(loc = mean, scale = sq_mean - mean^2): the variance is used as the scale, as written (SGLD.py:151-154)
             dist = TensorflowProbabilityDistribution(tfd.Normal(mean[sl].copy(), (sq_mean[sl] - mean[sl] ** 2).copy()))

@@ -40,15 +40,24 @@ class SVGD(Optimizer):
         self._prior = kwargs["prior"]
         self._M = int(self._hyperparameters.M)
         self._lr = self._hyperparameters.lr
-        self._gamma = float(kwargs.get("gamma", 1.0))           # SVGD.py:183: gamma = 1 fixed in the reference
+        # SVGD.py:183: gamma = 1 fixed in the reference.  kernel="median" (or gamma=None) selects the median
+        # heuristic of SVGD.baseline__kernel (SVGD.py:165-181, dead code there): bandwidth from the median of the
+        # squared distances of the snapshot, hence the Jacobi sweep
+        self._gamma = None if kwargs.get("kernel", "rbf") == "median" else kwargs.get("gamma", 1.0)
+        if self._gamma is not None:
+            self._gamma = float(self._gamma)
         # particle sharding over ranks (one process per GPU); single process = the reference's sweep
         from .. import parallel
-        self._rank, self._world = parallel.world_info() if kwargs.get("shard", True) else (0, 1)
-        self._row0, self._n_local = parallel.shard_range(self._M, self._world, self._rank)
-        self._sweep = kwargs.get("sweep", "gauss_seidel" if self._world == 1 else "jacobi")
-        if self._world > 1 and self._sweep != "jacobi":
+        rank, world = parallel.world_info() if kwargs.get("shard", True) else (0, 1)
+        self._row0, self._n_local = parallel.shard_range(self._M, world, rank)
+        self._sweep = kwargs.get("sweep", "gauss_seidel" if (world == 1 and self._gamma is not None) else "jacobi")
+        if world > 1 and self._sweep != "jacobi":
             raise ValueError("sharded particles need the Jacobi sweep")
-        self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local)
+        if self._gamma is None and self._sweep != "jacobi":
+            raise ValueError("the median-heuristic kernel is evaluated on a snapshot: it needs the Jacobi sweep")
+        # every rank draws the same batches and the same particle initialisation: one base seed for all
+        self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local, chain_per_rank=False)
+        self._rank, self._world = rank, world
         self._base_model = self._net
         self._dataset_setup()
         self._num_particles = self._D
@@ -81,20 +90,31 @@ class SVGD(Optimizer):
         self._step += 1
         idx, b, _ = self._next_batch()
         from .. import parallel
+        # phase 1 -- the loss gradients -- needs the local rows only; phase 2 is the first reader of the gathered
+        # matrix.  Several ranks: the all-gather (the one exchange step of the path) runs on RCCL's stream while
+        # phase 1 computes, and the compute stream waits for it right before phase 2.
+        work = None
         if self._world > 1:
-            parallel.all_gather_rows(self._local, self._all)            # the one exchange step of the path
+            work = parallel.all_gather_rows(self._local, self._all, async_op=True)
             snapshot = self._all
         elif self._sweep == "jacobi":
             snapshot = self._all.clone()
         else:
             snapshot = self._all
-        self._plan.svgd_step(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._x_dev, self._y_dev,
-                             self._lr, self._gamma, self._step, self._loss_dev, sweep=self._sweep, batch=b, row_idx=idx)
+        self._plan.svgd_gradients(self._local, self._x_dev, self._y_dev, batch=b, row_idx=idx)
+        if work is not None:
+            work.wait()
+        self._plan.svgd_sweep(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
+                              self._step, self._loss_dev, sweep=self._sweep)
+        # the step's loss (sum over the LOCAL particles / M) stays on the device; several ranks: the sum over
+        # ranks is taken only on the steps that record it (SVGD.py:137-139) -- a per-step all-reduce would put a
+        # second collective on the critical path for a number nobody reads
+        record = self._step % 10 == 0                           # SVGD.py:137-139
         total_loss = self._loss_dev.clone()
-        if self._world > 1:
+        if self._world > 1 and (record or self._verbose):       # (the progress bar shows every step's loss)
             parallel.sum_over_ranks(total_loss)
-        loss = DeviceScalar(total_loss, 0)
-        if self._step % 10 == 0:                                # SVGD.py:137-139
+        loss = DeviceScalar(total_loss, 0)                      # several ranks, quiet, unrecorded step: this rank's share
+        if record:
             # SVGD.py:126-129 forwards the validation split through every particle on every step, but only
             # these steps keep the number: the forward runs when it is observable
             if self._val_n > 0:

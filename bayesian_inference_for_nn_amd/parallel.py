@@ -43,6 +43,20 @@ def world_info() -> Tuple[int, int]:
     return 0, 1
 
 
+def shared_seed(seed=None) -> int:
+    """A seed every rank agrees on: the given one, else rank 0's fresh entropy broadcast to all.
+    Sharded SVGD needs it (one batch permutation and one particle initialisation for all ranks:
+    SVGD.py:93-111 feeds every particle the same batch); independent chains derive theirs as seed + rank."""
+    s = int(seed) if seed is not None else int.from_bytes(os.urandom(6), "little")
+    rank, world = world_info()
+    if world > 1:
+        import torch.distributed as dist
+        box = [s]
+        dist.broadcast_object_list(box, src=0)
+        s = int(box[0])
+    return s
+
+
 def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     """(first row, row count) of this rank's contiguous shard; n_items must divide evenly."""
     if n_items % world != 0:
@@ -51,23 +65,26 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * n_local, n_local
 
 
-def all_gather_rows(local, out):
-    """out (world * n_local, D) <- concatenation of every rank's `local` (n_local, D)."""
+def all_gather_rows(local, out, async_op: bool = False):
+    """out (world * n_local, D) <- concatenation of every rank's `local` (n_local, D).
+    async_op (RCCL only): the gather runs on the communicator's own stream, ordered after the work already
+    queued on the current stream; returns a handle whose wait() makes the current stream wait for it -- what
+    lies between the call and wait() overlaps with the exchange.  Otherwise returns None (complete)."""
     import torch.distributed as dist
     rank, world = world_info()
     if world == 1:
         if out.data_ptr() != local.data_ptr():
             out.copy_(local)
-        return out
+        return None
     if dist.get_backend() == "gloo":           # CPU tests / several ranks sharing one GPU: staged through the host
         parts = [out[i * local.shape[0]:(i + 1) * local.shape[0]] for i in range(world)]
         tmp = [p.detach().cpu().clone() for p in parts]
         dist.all_gather(tmp, local.detach().cpu().contiguous())
         for p, t in zip(parts, tmp):
             p.copy_(t)
-    else:
-        dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+        return None
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=async_op)
+    return work if async_op else None
 
 
 def sum_over_ranks(t):
@@ -99,11 +116,13 @@ def merge_moment_chains(mean, sq_mean, n: int):
     import torch.distributed as dist
     if world_info()[1] == 1:
         return mean, sq_mean, n
-    w = torch.tensor([float(n)], dtype=mean.dtype, device=mean.device)
-    m, s = mean * w, sq_mean * w
+    staged = dist.get_backend() == "gloo" and mean.is_cuda      # gloo reduces host tensors
+    dev = "cpu" if staged else mean.device
+    w = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+    m, s = mean.to(dev, torch.float64) * w, sq_mean.to(dev, torch.float64) * w
     for t in (m, s, w):
         dist.all_reduce(t)
-    return m / w, s / w, int(round(float(w.item())))
+    return (m / w).to(mean.device, mean.dtype), (s / w).to(mean.device, mean.dtype), int(round(float(w.item())))
 
 
 def merge_sampled_chains(samples: Sequence, frequencies: Sequence[int]) -> Tuple[List, List[int]]:

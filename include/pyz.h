@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYZ_VERSION 100 /* 0.1.0 */
+#define PYZ_VERSION 200 /* 0.2.0 */
 
 #define PYZ_OK 0
 #define PYZ_E_INVALID (-1) /* bad argument / unsupported combination */
@@ -42,6 +42,7 @@ extern "C" {
 #define PYZ_E_HIP (-3)     /* HIP runtime error (message has the HIP string) */
 #define PYZ_E_OOM (-4)     /* device allocation failed */
 #define PYZ_E_NODEV (-5)   /* no gfx950 device visible */
+#define PYZ_E_NAN (-6)     /* pyz_check_finite: a step produced a NaN / Inf loss */
 
 /* activations of a Dense layer (Keras names) */
 #define PYZ_ACT_LINEAR 0
@@ -53,6 +54,11 @@ extern "C" {
 /* losses produced by Dataset.loss() (Pyesian/datasets/Dataset.py:152-159) */
 #define PYZ_LOSS_SCCE 0 /* SparseCategoricalCrossentropy on a softmax last layer; labels int32 (B) */
 #define PYZ_LOSS_MSE 1  /* MeanSquaredError; targets float32 (B, out) */
+
+/* SVGD bandwidth: pass this as `gamma` for the median heuristic of SVGD.baseline__kernel (SVGD.py:165-181):
+ * h = sqrt(0.5 median(sqdist) / log(M + 1)), K = exp(-sqdist / (2 h^2)), repulsion (-K X + X rowsum K) / h^2,
+ * evaluated on the snapshot d_all (PYZ_SWEEP_JACOBI, at most 64 particles, counts in multiples of four). */
+#define PYZ_SVGD_GAMMA_MEDIAN (-1.0f)
 
 /* SVGD sweep order */
 #define PYZ_SWEEP_GAUSS_SEIDEL 0 /* the reference: particle i sees updated rows 0..i-1 (SVGD.py:100-123) */
@@ -142,14 +148,27 @@ int pyz_swag_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, 
                  const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
                  int64_t slot0, float *d_losses, int use_graph, void *stream);
 
-/* Measurement (bench.py roofline leg): n_steps eager SGLD steps, same arguments and effect as
- * pyz_sgld_run, with HIP events recorded on `stream` around the kernels of every step.
- * h_avg_us[3] = average in-pipeline duration in microseconds (launch gap included) of
- * {hidden-layer forward kernel(s), k_head, data-gradient kernels + k_wgrad_all}. */
-int pyz_sgld_profile(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean,
-                     const float *d_x, const void *d_y, const int32_t *d_row_idx,
-                     const int32_t *h_batch_sizes, const float *h_lr, int n_steps, int64_t n0,
-                     int64_t slot0, uint64_t seed, float *d_losses, float *h_avg_us, void *stream);
+/* What the last pyz_sgld_run / pyz_sgd_run / pyz_swag_run call on this plan did: steps that ran inside replayed
+ * hipGraphs, steps launched eagerly, and the number of graph launches.  With use_graph != 0 on a non-NULL
+ * stream a run of any length is replayed from graphs of 32, 16, 8, 4, 2 and 1 steps (PYZ_GRAPH_STEPS = 32). */
+int pyz_last_run_info(const pyz_mlp *mlp, int32_t *h_graph_steps, int32_t *h_eager_steps,
+                      int32_t *h_graph_launches);
+
+/* Non-finite sentinel (the reference prints the loss every step, Optimizer.py:123, so a diverged chain is
+ * seen at once; here losses stay on the device): every kernel that finalises a step's loss counts NaN / Inf
+ * results.  Synchronises `stream`, returns PYZ_E_NAN if any step since the last call was non-finite (the
+ * count is in the message) and resets the count. */
+int pyz_check_finite(pyz_mlp *mlp, void *stream);
+
+/* Measurement (bench.py roofline leg): between pyz_probe_begin and pyz_probe_end every kernel the calling
+ * thread launches through this library carries a start / stop event pair of its own (hipExtLaunchKernelGGL:
+ * the dispatch's begin / end timestamps, i.e. the duration rocprofv3 --kernel-trace reports; no packet is
+ * added between the kernels of a pipeline).  While a probe is open the *_run entry points launch eagerly.
+ * pyz_probe_end synchronises `stream` and returns, in launch order, each launch's duration in microseconds
+ * (h_us[max_launches]) and the kernel expression of its launch site (h_names: max_launches rows of
+ * name_stride bytes, NUL terminated; may be NULL); *h_n = launches recorded. */
+int pyz_probe_begin(int max_launches);
+int pyz_probe_end(void *stream, float *h_us, char *h_names, int name_stride, int *h_n);
 
 /* ---- B2-B4: BBB.step (BBB.py:128-201).  d_mu / d_rho are the variational
  * parameters (D each); eps ~ N(0,1) from Philox (seed, step) or d_eps.
@@ -189,17 +208,27 @@ int pyz_hmc_step(pyz_mlp *mlp, float *d_q, int n_chains, const float *d_x, const
  * (M, D) is the matrix the kernel row is evaluated against (== d_particles on
  * one GPU; the all-gathered snapshot under PYZ_SWEEP_JACOBI).  d_adam_m/v are
  * the Keras-legacy-Adam slots (P_local, D); t is the 1-based Adam step.  The
- * squared distances and the RBF kernel are evaluated in float64.  gamma > 0 is
- * the fixed bandwidth (reference: 1.0).  d_loss[0] = sum_i loss_i / M over the
+ * squared distances, the RBF kernel and the repulsion sum are evaluated in float64.  gamma > 0 is
+ * the fixed bandwidth (reference: 1.0); PYZ_SVGD_GAMMA_MEDIAN selects the median heuristic.  d_loss[0] = sum_i loss_i / M over the
  * local rows.  Under PYZ_SWEEP_JACOBI with M <= 64 and local rows in multiples of four (row0 too) the
  * sweep reads the particle matrix once per pass for all rows (squared distances through the Gram matrix on the
  * float64 matrix cores); a shard then gets the rows of the whole-matrix call.  Under PYZ_SWEEP_GAUSS_SEIDEL with M <= 64 and D <= 196 608 the sweep is one launch
- * per particle that reads the matrix once (repulsion sum in float32: phi is a float32 quantity); otherwise
- * two launches per particle (repulsion sum in float64).  The paths agree within float32 rounding of phi. */
+ * per particle that reads the matrix once; otherwise two launches per particle.  The paths agree within
+ * float32 rounding of phi. */
 int pyz_svgd_step(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total,
                   int row0, float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y,
                   const int32_t *d_row_idx, int batch, float lr, float gamma, int64_t t, int sweep,
                   float *d_loss, void *stream);
+
+/* The two phases of pyz_svgd_step as calls of their own, for callers that overlap the exchange of the particle
+ * matrix (the RCCL all-gather of the Jacobi sweep) with phase 1: pyz_svgd_gradients computes the loss gradients
+ * of the local particles (SVGD.py:104-111; they stay inside the plan) and needs no other rank's rows;
+ * pyz_svgd_sweep does the rest (kernel rows, repulsion, Adam, d_loss) and is the first reader of d_all. */
+int pyz_svgd_gradients(pyz_mlp *mlp, const float *d_particles, int n_local, const float *d_x, const void *d_y,
+                       const int32_t *d_row_idx, int batch, void *stream);
+int pyz_svgd_sweep(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                   float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, int sweep, float *d_loss,
+                   void *stream);
 
 /* ---- R1: BayesianModel.predict (BayesianModel.py:106-129): S weight draws
  * d_weights (S, D) -> d_samples (S, n, out) with NaN -> 0, d_mean (n, out). */
@@ -219,6 +248,16 @@ int pyz_fill_normal(float *d_out, int64_t n, uint64_t seed, uint32_t stream_id, 
 int pyz_sample_normal_rows(float *d_out, int64_t n_rows, int64_t row_stride, int64_t col0, int64_t len,
                            const float *d_loc, const float *d_scale, uint64_t seed,
                            uint32_t stream_id, uint32_t first_draw, void *stream);
+
+/* ---- device memory for callers that have no allocator of their own (a TensorFlow / NumPy host process binding
+ * this library from the reference's step(), INTEGRATION.md route B; torch-ROCm callers pass their tensors'
+ * storage instead).  pyz_upload / pyz_download copy between a HOST buffer and device memory and return when
+ * the host buffer may be reused / holds the data; pyz_sync waits for `stream`. */
+int pyz_malloc(size_t bytes, void **d_out);
+int pyz_free(void *d_ptr);
+int pyz_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int pyz_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int pyz_sync(void *stream);
 
 /* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE kernel of the
  * gradient step on the workspace left by the last pyz_mlp_loss_grad call with the same

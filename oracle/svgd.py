@@ -87,19 +87,30 @@ def svgd_step(st: SVGDState, x, y, spec: MLPSpec, lr: float, gamma: float = 1.0,
               sweep: str = "gauss_seidel", x_val=None, y_val=None):
     """One ``SVGD.step``.  sweep = 'gauss_seidel' (the reference) or 'jacobi'
     (all particles updated from the same snapshot; the multi-GPU mode).
-    Returns dict(loss, val_loss, losses)."""
+    gamma = None / 'median': the median-heuristic bandwidth (``median_kernel``).
+    Returns dict(loss, val_loss, losses, phi): phi (M, D) is what each particle's Adam received."""
     M, _ = st.particles.shape
     dt = st.wdtype
     st.t += 1
     snapshot = st.particles.copy()
-    total, total_val, losses = 0.0, 0.0, []
+    total, total_val, losses, phis = 0.0, 0.0, [], []
+    median = gamma is None or gamma == "median"
+    if median:
+        # the opt-in bandwidth: SVGD.baseline__kernel (SVGD.py:165-181) evaluated once on the snapshot, as in the
+        # code it was taken from (all particles move from the same kernel matrix): Jacobi sweep only
+        assert sweep == "jacobi", "the median-heuristic kernel is defined on a snapshot (Jacobi sweep)"
+        K_med, dx_med, _ = median_kernel(snapshot)
     for i in range(M):
         theta_i = st.particles[i].astype(dt)                                # SVGD.py:101
         loss, g_i, _ = loss_and_grad(theta_i, x, y, spec, dt)               # SVGD.py:104-111
         src = st.particles if sweep == "gauss_seidel" else snapshot
-        k, rep = rbf_row(src, i, gamma)                                      # SVGD.py:55-61
+        if median:
+            k, rep = K_med[i], dx_med[i]                                     # SVGD.py:172-180, row i
+        else:
+            k, rep = rbf_row(src, i, gamma)                                  # SVGD.py:55-61
         k = k.astype(dt)
         phi = (k.sum() * g_i + rep.astype(dt)) / dt(M)                       # SVGD.py:64-68
+        phis.append(phi)
         new_theta, st.m[i], st.v[i] = adam_update(theta_i, phi, st.m[i], st.v[i], st.t, lr, dt)
         st.particles[i] = new_theta.astype(np.float64)                       # SVGD.py:122-123
         total += loss / M                                                    # SVGD.py:125
@@ -107,7 +118,7 @@ def svgd_step(st: SVGDState, x, y, spec: MLPSpec, lr: float, gamma: float = 1.0,
         if x_val is not None:                                                # SVGD.py:126-129
             acts, logits = forward(new_theta, x_val, spec, dt)
             total_val += loss_value(acts[-1], logits, y_val, spec) / M
-    return dict(loss=total, val_loss=total_val, losses=np.array(losses))
+    return dict(loss=total, val_loss=total_val, losses=np.array(losses), phi=np.stack(phis))
 
 
 def median_kernel(particles64: np.ndarray, h: float = -1):

@@ -1,0 +1,106 @@
+"""INTEGRATION.md route B is executable documentation: the ctypes stubs a maintainer would paste into the
+reference's step() methods.  CPU: the argtypes table of the document equals include/pyz.h (through
+_lib.SIGNATURES).  GPU: the blocks run as written -- raw ctypes.CDLL, NumPy buffers, no torch, no engine.py --
+and one SGLD step + one HMC proposal match the oracle."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def doc_blocks():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n# \[integration:(\w+)\]\n(.*?)```", text, flags=re.S)
+    assert [b[0] for b in blocks] == ["load", "plan", "sgld", "hmc"], [b[0] for b in blocks]
+    return blocks
+
+
+def run_doc(names):
+    from bayesian_inference_for_nn_amd import _lib
+    _lib.load()                              # builds the library if needed
+    ns = {"LIB": _lib.lib_path()}
+    for name, code in doc_blocks():
+        if name in names:
+            exec(compile(code, f"INTEGRATION.md[{name}]", "exec"), ns)
+    return ns
+
+
+def test_documented_argtypes_match_the_header():
+    from bayesian_inference_for_nn_amd import _lib
+    ns = run_doc(["load"])
+    assert set(ns["ARGTYPES"]) >= {"pyz_mlp_create", "pyz_sgld_step", "pyz_hmc_step", "pyz_malloc", "pyz_upload", "pyz_download"}
+    for name, args in ns["ARGTYPES"].items():
+        res, ref = _lib.SIGNATURES[name]
+        assert res is C.c_int, name
+        assert len(args) == len(ref), f"{name}: the document lists {len(args)} arguments, the header {len(ref)}"
+        for k, (a, b) in enumerate(zip(args, ref)):
+            assert C.sizeof(a) == C.sizeof(b) and (a is b or a._type_ == b._type_), f"{name} argument {k}: {a} vs {b}"
+
+
+def test_documented_stubs_reject_bad_arguments_without_a_gpu():
+    ns = run_doc(["load", "plan"])
+    with pytest.raises(RuntimeError):
+        ns["make_plan"]((4, 2), (9,), 0, 8)          # unknown activation: PYZ_E_INVALID + message, no device touched
+
+
+@pytest.mark.gpu
+def test_route_b_sgld_step_and_hmc_proposal_match_the_oracle(gpu_device):
+    from oracle import hmc as o_hmc, mlp as o_mlp, philox as o_philox, sgld as o_sgld
+    ns = run_doc(["load", "plan", "sgld", "hmc"])
+    pyz, check, to_device, to_host = ns["pyz"], ns["check"], ns["to_device"], ns["to_host"]
+
+    # ---- SGLD.step on 24 -> 16 -> 4, a gathered batch of 50 rows out of 120
+    spec = o_mlp.MLPSpec((24, 16, 4), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(120, 24)).astype(np.float32)
+    y = rng.integers(0, 4, size=120).astype(np.int32)
+    theta0 = (rng.normal(size=spec.n_params) * 0.3).astype(np.float32)
+    idx = rng.permutation(120)[:50].astype(np.int32)
+    D = spec.n_params
+    h = ns["make_plan"](spec.dims, (1, 4), 0, 64)
+    d_theta, d_mean, d_sq = to_device(theta0), to_device(np.zeros(D, np.float32)), to_device(np.zeros(D, np.float32))
+    d_x, d_y, d_idx, d_loss = to_device(x), to_device(y), to_device(idx), to_device(np.zeros(1, np.float32))
+    st = o_sgld.SGLDState(theta0)
+    for n in range(3):
+        ns["sgld_step"](h, d_theta, d_mean, d_sq, d_x, d_y, d_idx, 50, 0.01, n, 11, d_loss)
+        rl, _ = o_sgld.sgld_step(st, x[idx], y[idx], spec, np.float32(0.01), o_philox.normal(11, 0, n, D))
+        assert abs(float(to_host(d_loss, (1,))[0]) - rl) <= 1e-4 * abs(rl)
+    for d, ref in ((d_theta, st.theta), (d_mean, st.mean), (d_sq, st.sq_mean)):
+        got = to_host(d, (D,))
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    check(pyz.pyz_check_finite(h, None))
+    # a NaN weight is reported by the sentinel, not silently carried along
+    bad = theta0.copy()
+    bad[0] = np.nan
+    check(pyz.pyz_upload(d_theta, bad.ctypes.data_as(C.c_void_p), bad.nbytes, None))
+    ns["sgld_step"](h, d_theta, d_mean, d_sq, d_x, d_y, d_idx, 50, 0.01, 3, 11, d_loss)
+    assert pyz.pyz_check_finite(h, None) == -6 and b"NaN" in pyz.pyz_last_error()
+    assert pyz.pyz_check_finite(h, None) == 0                     # the count was reset
+    for d in (d_theta, d_mean, d_sq, d_x, d_y, d_idx, d_loss):
+        check(pyz.pyz_free(d))
+    check(pyz.pyz_mlp_destroy(h))
+
+    # ---- HMC.step on 2 -> 50 -> 2, 300 rows, two chains, L = 5
+    spec = o_mlp.MLPSpec((2, 50, 2), ("relu", "softmax"), "scce")
+    x = rng.normal(size=(300, 2)).astype(np.float32)
+    y = rng.integers(0, 2, size=300).astype(np.int32)
+    D = spec.n_params
+    q0 = (rng.normal(size=(2, D)) * 0.2).astype(np.float32)
+    h = ns["make_plan"](spec.dims, (1, 4), 0, 300, 2)
+    d_q, d_x, d_y, d_stats = to_device(q0), to_device(x), to_device(y), to_device(np.zeros((2, 8), np.float32))
+    ns["hmc_step"](h, d_q, 2, d_x, d_y, 300, 5, 0.002, 0.5, 0.0, 1.0, True, [0.0, 0.0], 0, 77, d_stats)
+    q1, stats = to_host(d_q, (2, D)), to_host(d_stats, (2, 8))
+    for c in range(2):
+        z = o_philox.normal(77, 2 + 16 * c, 0, D)       # the momentum stream of chain c (csrc/pyz_rng.h), step 0
+        r = o_hmc.hmc_step(q0[c], z, x, y, spec, 0.0, 1.0, 5, 0.002, 0.5, u=0.0, burning=True)
+        assert stats[c, 0] == 1.0
+        assert np.abs(q1[c] - r["q_proposed"]).max() <= 1e-4 * np.abs(r["q_proposed"]).max()
+        assert abs(stats[c, 2] - r["U0"]) <= 1e-4 * abs(r["U0"])
+    for d in (d_q, d_x, d_y, d_stats):
+        check(pyz.pyz_free(d))
+    check(pyz.pyz_mlp_destroy(h))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): time the headline SGLD step with an alternative build of the library.
 usage: python tools/variants.py <path-to-lib.so> [label]    (env switches of the library apply)
-Prints one JSON line: graph-replay us/step and the in-pipeline kernel durations (HIP events)."""
+Prints one JSON line: graph-replay us/step and the per-kernel durations (engine.KernelProbe)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,11 +33,11 @@ with torch.cuda.stream(st):
     plan.sgld_run(theta, mean, sq, x, y, idx, sizes[256:], lrs[256:], 256, 1, losses, use_graph=True, slot0=256)
     st.synchronize()
     dt = time.perf_counter() - t0
-    plan.sgld_profile(theta, mean, sq, x, y, idx, sizes[:16], lrs[:16], n, 1, losses)
-    us = plan.sgld_profile(theta, mean, sq, x, y, idx, sizes[:256], lrs[:256], n + 16, 1, losses)
+    plan.sgld_run(theta, mean, sq, x, y, idx, sizes[:16], lrs[:16], n, 1, losses, use_graph=False)
+    with engine.KernelProbe(1024) as kp:
+        plan.sgld_run(theta, mean, sq, x, y, idx, sizes[:256], lrs[:256], n + 16, 1, losses, use_graph=False)
 step_us = dt / 2048 * 1e6
-k = 3
-ov = max(0.0, (sum(us[:k]) - step_us) / k)
+us = [round(v[1], 2) for v in kp.by_kernel().values()]
 print(json.dumps({"label": label, "us_per_step": round(step_us, 2), "steps_per_s": round(1e6 / step_us),
-                  "kernels_us": [round(v - ov, 2) for v in us[:k]], "loss": round(float(losses[n - 1].item()), 5),
+                  "kernels_us": us, "loss": round(float(losses[n - 1].item()), 5),
                   "env": {k_: v for k_, v in os.environ.items() if k_.startswith("PYZ_")}}), flush=True)
