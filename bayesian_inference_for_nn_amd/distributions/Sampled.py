@@ -43,18 +43,31 @@ class Sampled(Distribution):
         return np.stack([self.sample() for _ in range(n)])
 
     def store(self, path: str):
+        """info.json + samples/sample<i>.tf, each sample a serialized TensorProto: what tf.io.serialize_tensor /
+        tf.io.write_file leave there in the reference (Sampled.py:34-48), so either side loads the other's model."""
+        from .tensorproto import serialize_tensor
         info = {"size": self._size, "n_samples": self._n_samples, "frequencies": self._frequencies,
-                "dtypes": ["float32"] * self._n_samples}
+                "dtypes": [s.dtype.name for s in self._samples]}
         with open(os.path.join(path, "info.json"), "w") as f:
             f.write(json.dumps(info))
         sample_path = os.path.join(path, "samples")
         os.makedirs(sample_path, exist_ok=True)
         for i, s in enumerate(self._samples):
-            np.save(os.path.join(sample_path, "sample" + str(i) + ".npy"), s)
+            with open(os.path.join(sample_path, "sample" + str(i) + ".tf"), "wb") as f:
+                f.write(serialize_tensor(s))
 
     @classmethod
     def load(cls, path: str) -> "Distribution":
+        from .tensorproto import parse_tensor
         with open(os.path.join(path, "info.json"), "r") as f:
             info = json.load(f)
-        samples = [np.load(os.path.join(path, "samples", "sample" + str(i) + ".npy")) for i in range(info["n_samples"])]
+        sample_dir = os.path.join(path, "samples")
+        samples = []
+        for i in range(info["n_samples"]):
+            tf_file = os.path.join(sample_dir, "sample" + str(i) + ".tf")
+            if os.path.exists(tf_file):                                    # Sampled.py:50-60
+                with open(tf_file, "rb") as f:
+                    samples.append(parse_tensor(f.read(), info["dtypes"][i]))
+            else:                                                          # models stored by round 1 of this package
+                samples.append(np.load(os.path.join(sample_dir, "sample" + str(i) + ".npy")))
         return Sampled(samples, info["frequencies"])

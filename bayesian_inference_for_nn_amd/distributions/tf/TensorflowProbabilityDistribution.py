@@ -44,19 +44,26 @@ class TensorflowProbabilityDistribution(Distribution):
         return False
 
     def store(self, path: str):
+        """distribution.json = {"type": <tfp class name>, "params": <its constructor parameters>}: the schema of the
+        reference's BaseSerializer (distributions/tf/BaseSerializer.py:20-34), tfp's own bookkeeping parameters
+        included, so that BaseSerializer.deserialize can rebuild the tfp object from a model stored here."""
         d = self._tf_distribution
-        data = {"type": type(d).__name__, "loc": np.asarray(d.loc).tolist()}
+        params = {"loc": np.asarray(d.loc).tolist()}
         if isinstance(d, tfd.Normal):
-            data["scale"] = np.asarray(d.scale).tolist()
+            params["scale"] = np.asarray(d.scale).tolist()
+        elif isinstance(d, tfd.Deterministic):
+            params.update(atol=None, rtol=None)
+        params.update(validate_args=False, allow_nan_stats=True, name=type(d).__name__)
         with open(os.path.join(path, "distribution.json"), "w") as f:
-            f.write(json.dumps(data))
+            f.write(json.dumps({"type": type(d).__name__, "params": params}))
 
     @classmethod
     def load(cls, path: str) -> "Distribution":
         with open(os.path.join(path, "distribution.json"), "r") as f:
             data = json.load(f)
+        params = data.get("params", data)            # (round 1 of this package wrote loc / scale at the top level)
         if data["type"] == "Normal":
-            return cls(tfd.Normal(np.asarray(data["loc"], np.float32), np.asarray(data["scale"], np.float32)))
+            return cls(tfd.Normal(np.asarray(params["loc"], np.float32), np.asarray(params["scale"], np.float32)))
         if data["type"] == "Deterministic":
-            return cls(tfd.Deterministic(np.asarray(data["loc"], np.float32)))
+            return cls(tfd.Deterministic(np.asarray(params["loc"], np.float32)))
         raise ValueError("unknown distribution type " + str(data["type"]))

@@ -153,15 +153,8 @@ class BayesianModel:
         return bayesian_model
 
     def _empty_folder(self, path):
-        for filename in os.listdir(path):
-            file_path = os.path.join(path, filename)
-            try:
-                if os.path.isfile(file_path) or os.path.islink(file_path):
-                    os.unlink(file_path)
-                elif os.path.isdir(file_path):
-                    shutil.rmtree(file_path)
-            except Exception as e:
-                print('Failed to delete %s. Reason: %s' % (file_path, e))
+        from .._fs import empty_folder
+        empty_folder(path)
 
     def store(self, model_path: str):
         """Directory format of BayesianModel.py:177-203: config.json, layers_config.txt

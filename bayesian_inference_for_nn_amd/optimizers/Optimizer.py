@@ -77,15 +77,8 @@ class Optimizer(ABC):
         pass
 
     def _empty_folder(self, path):
-        for filename in os.listdir(path):
-            file_path = os.path.join(path, filename)
-            try:
-                if os.path.isfile(file_path) or os.path.islink(file_path):
-                    os.unlink(file_path)
-                elif os.path.isdir(file_path):
-                    shutil.rmtree(file_path)
-            except Exception as e:
-                print('Failed to delete %s. Reason: %s' % (file_path, e))
+        from .._fs import empty_folder
+        empty_folder(path)
 
     def train_with_weights_and_biases(self, nb_iterations, project_name, weights_and_biases_config):
         raise RuntimeError("wandb is not available in this environment (no network)")
@@ -126,21 +119,18 @@ class Optimizer(ABC):
         return False
 
     def _print_progress(self, progress: float, bar_length=10, suffix="Training", **kwargs):
+        """One carriage-returned status line: "<suffix> <pct> % [====>     ] key: value ..." (the text the
+        reference shows, Optimizer.py:149-160)."""
         if not self._verbose:
             return
-        nb_chars = math.ceil(progress * bar_length)
-        bar = "[" + nb_chars * "="
-        if nb_chars < bar_length:
-            bar += ">"
-        bar += "]"
-        infos = ' '.join("{}: {}".format(k, v) for k, v in kwargs.items())
-        percentage = str(math.ceil(progress * 100))
-        print("\r" + suffix + " " + percentage + " % " + bar + " " + infos, end="")
+        filled = math.ceil(progress * bar_length)
+        bar = "[" + "=" * filled + (">" if filled < bar_length else "") + "]"
+        fields = " ".join(f"{k}: {v}" for k, v in kwargs.items())
+        print(f"\r{suffix} {math.ceil(progress * 100)} % {bar} {fields}", end="")
 
     def _new_progress_line(self):
-        if not self._verbose:
-            return
-        print()
+        if self._verbose:
+            print()
 
     # ------------------------------------------------------------------ device-resident data
     def _setup_backend(self, seed=None, max_particles=1, full_batch=False, chain_per_rank=True):

@@ -94,3 +94,19 @@ def _merges(rank, world):
 
 def test_chain_merges_and_shard_ranges():
     assert all(run2(_merges))
+
+
+def _seeds(rank, world):
+    from bayesian_inference_for_nn_amd import parallel
+    from bayesian_inference_for_nn_amd.datasets import Dataset
+    from bayesian_inference_for_nn_amd.losses import MeanSquaredError
+    fresh = parallel.shared_seed(None)            # rank 0's entropy, the same on every rank
+    given = parallel.shared_seed(7 + rank)        # rank 0's argument wins
+    x = np.arange(200.0).reshape(100, 2)
+    ds = Dataset((x, x[:, :1]), MeanSquaredError, "Regression")     # seed=None: one split for all ranks
+    return fresh, given, ds.train_data.x[:5].tolist()
+
+
+def test_shared_seed_and_dataset_split_agree_across_ranks():
+    a, b = run2(_seeds)
+    assert a[0] == b[0] and a[1] == b[1] == 7 and a[2] == b[2]

@@ -1,0 +1,122 @@
+"""The N > 1 paths THROUGH THE OPTIMIZERS with real kernels: two ranks (gloo rendezvous; both sit on the one GPU of
+the test box) drive the drop-in surface.
+
+  * sharded SVGD compiled with seed=None: rank 0's entropy is broadcast, so both ranks draw the same data split,
+    batch permutation and particle initialisation; the sharded run (all-gather per step, gradient pass / sweep
+    split around it) reproduces the unsharded Jacobi run bit for bit;
+  * SGLD / HMC chains: one chain per rank with distinct seeds, no data-path collective; result() pools the running
+    moments (SGLD.py:143-165) / concatenates the chains' samples and frequencies (HMC.py:176-187) on every rank."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _scenario(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _scenario(rank, world):
+    import random
+    from bayesian_inference_for_nn_amd import parallel, synth
+    from bayesian_inference_for_nn_amd.datasets import Dataset
+    from bayesian_inference_for_nn_amd.distributions import GaussianPrior
+    from bayesian_inference_for_nn_amd.losses import SparseCategoricalCrossentropy
+    from bayesian_inference_for_nn_amd.nn import sequential_json
+    from bayesian_inference_for_nn_amd.optimizers import HMC, SGLD, SVGD
+    from bayesian_inference_for_nn_amd.optimizers.hyperparameters import HyperParameters
+    out = {}
+    cfg = sequential_json(2, [16, 2], ["relu", "softmax"])
+    x, y = synth.moons(500, seed=42)
+    ds = Dataset((x, y), SparseCategoricalCrossentropy, "Classification")          # seed=None: shared through rank 0
+    out["split_head"] = ds.train_data.x[:4].tolist()
+
+    # ---- SVGD, particles sharded 4 + 4, seed=None
+    opt = SVGD()
+    opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3))
+    assert (opt._world, opt._n_local, opt._row0, opt._sweep) == (2, 4, 4 * rank, "jacobi")
+    out["svgd_seed"] = opt._seed
+    out["svgd_init"] = opt._all.cpu().numpy().tolist()
+    rows = []
+    for _ in range(6):
+        opt.step()
+        rows.append(opt._perm_host[:8].tolist())
+    out["svgd_rows"] = rows
+    ens, _, _ = opt.result()
+    sharded = np.stack([m.weights_flat for m in ens])
+    whole_opt = SVGD()                                                              # the same run, unsharded, on this rank
+    whole_opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3),
+                      seed=opt._seed, shard=False, sweep="jacobi")
+    for _ in range(6):
+        whole_opt.step()
+    whole = np.stack([m.weights_flat for m in whole_opt.result()[0]])
+    out["svgd_diff"] = float(np.abs(sharded - whole).max())
+
+    # ---- SGLD: a chain per rank, pooled moments in result()
+    sg = SGLD()
+    sg.compile(HyperParameters(lr_upper=0.01, lr_lower=0.003, lr_gamma=0.99, batch_size=100), cfg, ds, verbose=False, seed=11)
+    out["sgld_seed"] = sg._seed
+    sg.train(8 + 4 * rank)                                                          # chains of different length: weighted pooling
+    local_mean = sg._mean_dev.cpu().numpy().astype(np.float64)
+    bm = sg.result()
+    out["sgld_local_mean"] = local_mean.tolist()
+    out["sgld_n"] = sg._n
+    out["sgld_pooled_steps"] = sg.pooled_steps
+    out["sgld_merged_loc"] = np.concatenate([d._tf_distribution.loc for d in bm._distributions]).tolist()
+
+    # ---- HMC: a chain per rank, one Sampled posterior over both in result()
+    random.seed(100 + rank)
+    hm = HMC()
+    hm.compile(HyperParameters(epsilon=0.002, m=0.5, L=4), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 1.0), seed=21)
+    hm.train(5)
+    out["hmc_local_freq"] = list(hm._frequency)
+    post = hm.result()._distributions[0]
+    out["hmc_merged_freq"] = list(post._frequencies)
+    out["hmc_merged_first"] = [float(s[0]) for s in post._samples]
+    return out
+
+
+def test_two_ranks_through_the_optimizers(gpu_device):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    # one split, one seed, one particle initialisation, one batch order on both ranks although nothing was seeded
+    assert a["split_head"] == b["split_head"] and a["svgd_seed"] == b["svgd_seed"]
+    assert a["svgd_init"] == b["svgd_init"] and a["svgd_rows"] == b["svgd_rows"]
+    # sharded == whole-matrix Jacobi, same kernels in the same order
+    assert a["svgd_diff"] == 0.0 and b["svgd_diff"] == 0.0
+    # SGLD: distinct chains, the pooled first moment is the step-weighted mean of the two
+    assert a["sgld_seed"] + 1 == b["sgld_seed"] and (a["sgld_n"], b["sgld_n"]) == (8, 12)
+    pooled = (8 * np.asarray(a["sgld_local_mean"]) + 12 * np.asarray(b["sgld_local_mean"])) / 20
+    assert a["sgld_pooled_steps"] == b["sgld_pooled_steps"] == 20
+    for r in (a, b):
+        np.testing.assert_allclose(r["sgld_merged_loc"], pooled, rtol=0, atol=1e-6 * np.abs(pooled).max())
+    assert not np.allclose(a["sgld_local_mean"], b["sgld_local_mean"])
+    # HMC: both ranks hold the concatenation (rank order) of the two chains
+    assert sum(a["hmc_local_freq"]) == sum(b["hmc_local_freq"]) == 6
+    assert a["hmc_merged_freq"] == b["hmc_merged_freq"] == a["hmc_local_freq"] + b["hmc_local_freq"]
+    assert a["hmc_merged_first"] == b["hmc_merged_first"]

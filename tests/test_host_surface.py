@@ -130,6 +130,72 @@ def test_store_load_roundtrip(tmp_path):
     assert back._distributions[1]._frequencies == [3, 1]
 
 
+def test_stored_leaves_have_the_reference_formats(tmp_path):
+    """distribution<i>/ holds what the reference's own store() writes: distribution.json = {"type", "params"}
+    (distributions/tf/BaseSerializer.py:20-34) and info.json + samples/sample<i>.tf, a serialized TensorProto
+    (distributions/Sampled.py:34-48)."""
+    from bayesian_inference_for_nn_amd.distributions import tensorproto
+    bm = _bm()
+    bm.apply_distribution(TensorflowProbabilityDistribution(tfd.Normal(np.arange(15.0), np.full(15, 0.1))), 1, 1)
+    bm.apply_distribution(Sampled([np.zeros(8), np.arange(8.0)], [3, 1]), 2, 2)
+    p = str(tmp_path / "saved")
+    bm.store(p)
+    dj = json.load(open(os.path.join(p, "distribution0", "distribution.json")))
+    assert dj["type"] == "Normal" and set(dj["params"]) >= {"loc", "scale", "validate_args", "allow_nan_stats", "name"}
+    assert dj["params"]["loc"] == list(np.arange(15.0)) and dj["params"]["name"] == "Normal"
+    info = json.load(open(os.path.join(p, "distribution1", "info.json")))
+    assert info == {"size": 8, "n_samples": 2, "frequencies": [3, 1], "dtypes": ["float32", "float32"]}
+    raw = open(os.path.join(p, "distribution1", "samples", "sample1.tf"), "rb").read()
+    # dtype DT_FLOAT, shape [8], 32 content bytes
+    assert raw[:10] == bytes([0x08, 0x01, 0x12, 0x04, 0x12, 0x02, 0x08, 0x08, 0x22, 0x20])
+    assert np.array_equal(tensorproto.parse_tensor(raw, "float32"), np.arange(8, dtype=np.float32))
+    # known answer from TensorFlow's TFRecord guide: tf.io.serialize_tensor of float32 [[1, 2, 3], [4, 5, 6]]
+    kat = b'\x08\x01\x12\x08\x12\x02\x08\x02\x12\x02\x08\x03"\x18' + np.arange(1, 7, dtype="<f4").tobytes()
+    assert tensorproto.serialize_tensor(np.arange(1, 7, dtype=np.float32).reshape(2, 3)) == kat
+    assert np.array_equal(tensorproto.parse_tensor(kat), np.arange(1, 7, dtype=np.float32).reshape(2, 3))
+    with pytest.raises(TypeError):
+        tensorproto.parse_tensor(kat, "float64")
+
+
+def test_loads_a_model_directory_laid_out_by_the_reference_and_the_round_one_form(tmp_path):
+    """A directory written the way BayesianModel.store / Sampled.store / BaseSerializer.serialize of the reference
+    write it (built here by hand from those formats: HMC result = one Sampled over all layers; a float64 sample in
+    the repeated-value TensorProto form; extra tfp parameters), and the leaves round 1 of this package wrote."""
+    from bayesian_inference_for_nn_amd.distributions import tensorproto
+    cfg = sequential_json(3, [4, 2], ["relu", "softmax"])
+    D = 3 * 4 + 4 + 4 * 2 + 2
+    p = tmp_path / "from_reference"
+    (p / "distribution0" / "samples").mkdir(parents=True)
+    (p / "config.json").write_text(cfg)
+    (p / "layers_config.txt").write_text("1\nSampled\n0\n" + str(BayesianModel(cfg)._n_layers - 1) + "\n")
+    s0 = np.linspace(-1, 1, D).astype(np.float32)
+    (p / "distribution0" / "info.json").write_text(json.dumps({"size": D, "n_samples": 2, "frequencies": [5, 2],
+                                                               "dtypes": ["float32", "float64"]}))
+    (p / "distribution0" / "samples" / "sample0.tf").write_bytes(tensorproto.serialize_tensor(s0))
+    # DT_DOUBLE, shape [D], double_val (field 6, packed): the form TensorProto takes when built from a value list
+    dv = np.full(D, 0.25, dtype="<f8").tobytes()
+    proto = bytes([0x08, 0x02, 0x12, 0x04, 0x12, 0x02, 0x08, D, 0x32]) + tensorproto._varint(len(dv)) + dv
+    (p / "distribution0" / "samples" / "sample1.tf").write_bytes(proto)
+    bm = BayesianModel.load(str(p))
+    d = bm._distributions[0]
+    assert isinstance(d, Sampled) and d._frequencies == [5, 2] and np.allclose(d._samples[0], s0) and np.allclose(d._samples[1], 0.25)
+    # tfp leaf with every parameter tfp records
+    q = tmp_path / "tfp_leaf"
+    q.mkdir()
+    (q / "distribution.json").write_text(json.dumps({"type": "Normal", "params": {
+        "loc": [0.0, 1.0], "scale": [0.5, 0.25], "validate_args": False, "allow_nan_stats": True, "name": "Normal"}}))
+    back = TensorflowProbabilityDistribution.load(str(q))
+    assert np.allclose(back._tf_distribution.scale, [0.5, 0.25])
+    # round-1 leaves of this package still load
+    (q / "distribution.json").write_text(json.dumps({"type": "Deterministic", "loc": [3.0, 4.0]}))
+    assert np.allclose(TensorflowProbabilityDistribution.load(str(q))._tf_distribution.loc, [3.0, 4.0])
+    r = tmp_path / "round1_sampled"
+    (r / "samples").mkdir(parents=True)
+    (r / "info.json").write_text(json.dumps({"size": 3, "n_samples": 1, "frequencies": [4], "dtypes": ["float32"]}))
+    np.save(r / "samples" / "sample0.npy", np.array([1, 2, 3], np.float32))
+    assert np.allclose(Sampled.load(str(r))._samples[0], [1, 2, 3])
+
+
 # ---------------------------------------------------------------- Dataset
 def test_dataset_split_and_loss_factory():
     x = np.arange(2000, dtype=np.float64).reshape(1000, 2)
