@@ -578,10 +578,8 @@ static inline int pyz_pick_waves(long long tiles, long long mfma_steps) {
 // them (predict, 100 draws x 10 000 rows: 18.0 ms; padded 14.6).  The padding workgroups own no tile.
 static inline unsigned pyz_pad8(long long n, int P) { return (unsigned)(P > 1 ? (n + 7) / 8 * 8 : n); }
 
-static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
-  const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.N + 31) / 32);
-  const int S = pyz_pick_waves(tiles * P, (g.K + 1) / 2 + 1);
-  // launches that fill the chip with one wave per tile (many particles / samples): the LDS-tiled kernel
+// launches that fill the chip with one wave per tile (many particles / samples) take the LDS-tiled forward
+static inline bool pyz_fwd_takes_lds(const DenseArgs &g, int grid_batch, int P, int S) {
   const int lds_on = pyz_env_int("PYZ_FWD_LDS", 1);  // read per call: tests flip it
   const bool lds_ok = g.K % 4 == 0 && g.N % 2 == 0 && g.lda % 4 == 0 && g.w_off % 2 == 0 && (P == 1 || g.theta_pstride % 2 == 0) &&
                       (P == 1 || g.in_pstride % 4 == 0) && (reinterpret_cast<uintptr_t>(g.theta) & 7) == 0 &&
@@ -590,7 +588,13 @@ static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hip
   // (measured: with few row tiles per particle -- C5: 8 -- the LDS kernel wins, 0.23 against 0.32 ms; with many --
   // predict, 79 -- the one-wave kernel runs out of an L2 that keeps its slice of the rows and wins, 14.5 against 16.7 ms)
   const int lds_max_rows = pyz_env_int("PYZ_FWD_LDS_MAXROWS", 2048);
-  if (S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows) {
+  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows;
+}
+
+static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {
+  const long long tiles = (long long)((grid_batch + 31) / 32) * ((g.N + 31) / 32);
+  const int S = pyz_pick_waves(tiles * P, (g.K + 1) / 2 + 1);
+  if (pyz_fwd_takes_lds(g, grid_batch, P, S)) {
     const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
     const long long tl = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT));
     const dim3 grid(pyz_pad8(tl, P), P), block(256);
