@@ -291,14 +291,6 @@ bool launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
     const int S = pyz_pick_waves(tiles * P, (fg.K + 1) / 2 + 1);
     const int nrb = cdiv(m->max_batch, 32);
     if (S == 16 && !pyz_fwd_takes_lds(fg, grid_batch, P, S)) {
-      if (!m->arrive) {
-        const size_t bytes = sizeof(int) * (size_t)m->max_p * nrb + 64;
-        if (hipMalloc((void **)&m->arrive, bytes) != hipSuccess || hipMemset(m->arrive, 0, bytes) != hipSuccess) {
-          m->arrive = nullptr;
-          return false;
-        }
-        m->ws_bytes += bytes;
-      }
       FwdHeadArgs fa{};
       fa.f = fg;
       fa.h = g;
@@ -516,6 +508,12 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   }
   if (hipMalloc((void **)&m->nonfinite, 64) != hipSuccess || hipMemset(m->nonfinite, 0, 64) != hipSuccess)
     return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
+  {  // arrival counters of k_fwd_head: one per (particle, 32-row block); a launch leaves them at zero
+    const size_t bytes = sizeof(int) * (size_t)max_particles * cdiv(max_batch, 32) + 64;
+    if (hipMalloc((void **)&m->arrive, bytes) != hipSuccess || hipMemset(m->arrive, 0, bytes) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
+    m->ws_bytes += bytes;
+  }
   if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
   if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
   const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
