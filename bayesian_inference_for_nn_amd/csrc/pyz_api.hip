@@ -238,11 +238,8 @@ void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, 
 // ---- fused path (pyz_fused.h): usable when the last layer fits one 32-wide tile
 inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
 
-// fwd == nullptr: the head as a launch of its own (returns true).  fwd given: try the fused launch of that
-// forward (the last hidden layer) + the head; false = not applicable, nothing was launched.
-bool launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
-                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st,
-                 const DenseArgs *fwd = nullptr) {
+void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
+                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st) {
   const int l = m->L - 1;
   HeadArgs g{};
   g.K = m->dims[l];
@@ -282,38 +279,12 @@ bool launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   static const int rows_on = pyz_env_int("PYZ_HEAD_ROWS", 1);
   const int UT = g.K <= 64 ? 1 : g.K <= 256 ? 4 : g.K <= 512 ? 8 : g.K <= 1024 ? 16 : 0;
   const int NP = g.N <= 4 ? 4 : g.N <= 8 ? 8 : g.N <= 12 ? 12 : g.N <= 16 ? 16 : g.N <= 24 ? 24 : 32;
-  // the last hidden layer and the head in one launch (k_fwd_head): the forward must be the 16-wave form of
-  // k_dense_fwd (one workgroup per CU: what the sc1 hand-off is measured for) and the head's lane-resident
-  // operands must leave room in a 1024-thread workgroup's 128 registers per lane
-  if (fwd && rows_on && UT && UT * NP <= 48 && NP <= 16) {
-    const DenseArgs &fg = *fwd;
-    const long long tiles = (long long)cdiv(grid_batch, 32) * cdiv(fg.N, 32);
-    const int S = pyz_pick_waves(tiles * P, (fg.K + 1) / 2 + 1);
-    const int nrb = cdiv(m->max_batch, 32);
-    if (S == 16 && !pyz_fwd_takes_lds(fg, grid_batch, P, S)) {
-      FwdHeadArgs fa{};
-      fa.f = fg;
-      fa.h = g;
-      fa.h.nblk = grid_batch;  // one loss partial per row
-      fa.arrive = m->arrive;
-      fa.nrb = nrb;
-      m->cur_nblk = grid_batch;
-      const dim3 grid(pyz_pad8(tiles, P), P), block(1024);
-#define PYZ_FWD_HEAD_CASE(U, C) \
-  if (UT == U && NP == C) { PYZ_LAUNCH((k_fwd_head<U, C>), grid, block, 16 * 4096, st, fa); return true; }
-      PYZ_FWD_HEAD_CASE(1, 4) PYZ_FWD_HEAD_CASE(1, 8) PYZ_FWD_HEAD_CASE(1, 12) PYZ_FWD_HEAD_CASE(1, 16)
-      PYZ_FWD_HEAD_CASE(4, 4) PYZ_FWD_HEAD_CASE(4, 8) PYZ_FWD_HEAD_CASE(4, 12)
-#undef PYZ_FWD_HEAD_CASE
-    }
-    return false;
-  }
-  if (fwd) return false;
   if (rows_on && UT && UT * NP <= 128) {
     g.nblk = grid_batch;  // one loss partial per row
     m->cur_nblk = g.nblk;
     const dim3 grid((unsigned)cdiv(grid_batch, 4), P), block(256);
 #define PYZ_HEAD_ROWS_CASE(U, C) \
-  if (UT == U && NP == C) { PYZ_LAUNCH((k_head_rows<U, C>), grid, block, 0, st, g); return true; }
+  if (UT == U && NP == C) { PYZ_LAUNCH((k_head_rows<U, C>), grid, block, 0, st, g); return; }
     PYZ_HEAD_ROWS_CASE(1, 4) PYZ_HEAD_ROWS_CASE(1, 8) PYZ_HEAD_ROWS_CASE(1, 12) PYZ_HEAD_ROWS_CASE(1, 16)
     PYZ_HEAD_ROWS_CASE(1, 24) PYZ_HEAD_ROWS_CASE(1, 32)
     PYZ_HEAD_ROWS_CASE(4, 4) PYZ_HEAD_ROWS_CASE(4, 8) PYZ_HEAD_ROWS_CASE(4, 12) PYZ_HEAD_ROWS_CASE(4, 16)
@@ -326,7 +297,6 @@ bool launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   m->cur_nblk = g.nblk;
   static const int head_waves = pyz_env_int("PYZ_HEAD_WAVES", 8) >= 8 ? 8 : 4;
   PYZ_LAUNCH(k_head, dim3(g.nblk, P), dim3(64 * head_waves), head_waves * 4096 + 2 * 32 * 33 * 4 + 64, st, g);
-  return true;
 }
 
 // data gradients of layers L-2 .. 1 (the head already produced delta[L-2])
@@ -403,16 +373,8 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
   if (can_fuse(m)) {
     static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 1);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
-    // hidden layers, then the head; the last hidden layer and the head share a launch where that form applies
-    const int fuse_on = pyz_env_int("PYZ_FUSE_HEAD", 1);  // read per call: tests flip it
-    bool fused = false;
-    if (m->L >= 2) {
-      launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb, m->L - 2);
-      const DenseArgs fg = forward_args(m, m->L - 2, theta, theta_ps, x, row_idx, ctl, xb);
-      if (fuse_on) fused = launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st, &fg);
-      if (!fused) pyz_launch_fwd(fg, grid_batch, P, st);
-    }
-    if (!fused) launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
+    launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb, m->L - 1);   // hidden layers
+    launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
     if (want_grad) {
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
       launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xb);
@@ -508,12 +470,6 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   }
   if (hipMalloc((void **)&m->nonfinite, 64) != hipSuccess || hipMemset(m->nonfinite, 0, 64) != hipSuccess)
     return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
-  {  // arrival counters of k_fwd_head: one per (particle, 32-row block); a launch leaves them at zero
-    const size_t bytes = sizeof(int) * (size_t)max_particles * cdiv(max_batch, 32) + 64;
-    if (hipMalloc((void **)&m->arrive, bytes) != hipSuccess || hipMemset(m->arrive, 0, bytes) != hipSuccess)
-      return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
-    m->ws_bytes += bytes;
-  }
   if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
   if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
   const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
@@ -537,7 +493,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite, m->arrive};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) {

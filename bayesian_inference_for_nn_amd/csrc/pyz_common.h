@@ -176,5 +176,4 @@ struct pyz_mlp {
   // what the last pyz_*_run call did: steps inside replayed graphs, eager steps, graph launches
   int run_graph_steps = 0, run_eager_steps = 0, run_graph_launches = 0;
   int *nonfinite = nullptr;                  // device counter: steps whose loss was NaN / Inf (pyz_check_finite)
-  int *arrive = nullptr;                     // (max_p, row blocks) arrival counters of k_fwd_head, zero between launches
 };

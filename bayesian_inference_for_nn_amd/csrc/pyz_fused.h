@@ -268,15 +268,8 @@ __device__ __forceinline__ float pyz_row16_allmax(float v) {
   return v;
 }
 
-// The head of ONE batch row m by ONE wave (lane l): shared by k_head_rows (one wave per row over the whole chip)
-// and k_fwd_head (the rows of a row block, by the workgroup that completed it).  SC1: the layer input was
-// written earlier in this SAME launch by other workgroups (sc1 stores): read it with sc1 loads (served by L2 /
-// the memory side, never by this CU's L1 -- MI355X_MICROARCH.md, inter-workgroup visibility).
-__device__ __forceinline__ float pyz_buf_load_sc1(const __amdgpu_buffer_rsrc_t rsrc, const unsigned voff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, 0, 16 /* sc1 */));
-}
-
-template <int UT, int NP, bool SC1>
+// The head of ONE batch row m by ONE wave (lane l).
+template <int UT, int NP>
 __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch, const long long row_off, const int p,
                                              const int m, const int l) {
   const int K = g.K, N = g.N;
@@ -295,7 +288,7 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
 #pragma unroll
   for (int t = 0; t < UT; ++t) {
     const int u = l + 64 * t;
-    hv[t] = SC1 ? pyz_buf_load_sc1(rh, 4u * (unsigned)u) : pyz_buf_load(rh, 4u * (unsigned)u, 0u);
+    hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
     // only the per-lane offset is range checked by the hardware (not the scalar one): units past K get an
     // out-of-range voffset; a padded class c >= N reads a neighbouring in-range element (or 0 past the
     // end), which is harmless: z[c] is never used and delta_L[c] = 0 multiplies it below
@@ -422,80 +415,7 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
     if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
     return;
   }
-  pyz_head_row<UT, NP, false>(g, batch, ctl.row_off, p, m, l);
-}
-
-// ---------------------------------------------------------------- last hidden layer + head in ONE launch
-// k_dense_fwd for the last hidden layer, and behind it -- without a kernel boundary -- the head of every row
-// block: the n-tiles of a 32-row block arrive on a per-block counter; the workgroup whose arrival completes the
-// block runs pyz_head_row on its rows (its waves take the rows in turn).  A step of the 2-layer model is then
-// two launches instead of three, and the head's own launch ramp, scalar loads and drain disappear (they were
-// 4.6 us of a 26 us step for 1.3 % of its arithmetic).
-// Inter-workgroup hand-off (MI355X_MICROARCH.md, Workgroup dispatch ... visibility; the first row of its table of
-// measured sc1 hand-offs): the tile's activations are stored sc1 (write-through), every storing wave waits for
-// its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the block's counter with a
-// returning agent-scope atomic; the workgroup whose add came last (told by the value returned) reads the block's
-// rows with sc1 loads only, its other waves behind a workgroup barrier that lane joins.  One workgroup per CU
-// (the launch requires 1024 threads).  The finishing workgroup puts the counter back to zero for the next launch.
-struct FwdHeadArgs {
-  DenseArgs f;      // forward of the last hidden layer (k_dense_fwd's arguments)
-  HeadArgs h;       // the head; h.hin is f.out
-  int *arrive;      // (P, row blocks) arrival counters, zero between launches
-  int nrb;          // row blocks the counters are laid out for
-};
-
-template <int UT, int NP>
-__global__ void __launch_bounds__(1024) k_fwd_head(FwdHeadArgs a) {
-  extern __shared__ float red[];
-  __shared__ int s_last;
-  const DenseArgs &g = a.f;
-  const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
-  const int r = l & 31, h = l >> 5;
-  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
-  const int batch = ctl.batch;
-  const int tiles_n = (g.N + 31) >> 5;
-  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
-  const int rb = tile / tiles_n, nt = tile % tiles_n;
-  const int m0 = rb * 32, n0 = nt * 32;
-  const int p = blockIdx.y;
-  if (m0 >= batch) {  // uniform per workgroup.  The head keeps one loss partial per row: rows past the batch hold zero
-    if (nt == 0 && threadIdx.x < 32 && m0 + (int)threadIdx.x < a.h.nblk) a.h.part[p * a.h.nblk + m0 + threadIdx.x] = 0.0;
-    return;
-  }
-  const int K = g.K, N = g.N;
-  const int m = min(m0 + r, batch - 1), n = min(n0 + r, N - 1);
-  long long row = m;
-  if (g.row_idx) row = g.row_idx[ctl.row_off + m];
-  const float *ap = g.in + p * g.in_pstride + row * g.lda;
-  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
-  f32x16 acc = {0};
-  float *gp = (g.gather_out && p == 0) ? g.gather_out + (long long)m * K : nullptr;
-  pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h, gp, tiles_n, nt);
-  float *op = g.out + p * g.out_pstride;
-  const int act = g.act;
-  pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
-    const int mm = m0 + ro, nn = n0 + co;
-    if (mm < batch && nn < N)
-      __hip_atomic_store(op + (long long)mm * N + nn, pyz_act(v, act), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
-  });
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's tile stores (and batch-copy stores) have left
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int *cnt = a.arrive + p * a.nrb + rb;
-    const int before = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = before == tiles_n - 1 ? 1 : 0;
-    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else touches it in this launch
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const int m_end = min(m0 + 32, batch);
-  if (threadIdx.x < 32) {  // rows of this block past the batch: their loss partials read as zero
-    const int mz = m0 + threadIdx.x;
-    if (mz >= batch && mz < a.h.nblk) a.h.part[p * a.h.nblk + mz] = 0.0;
-  }
-#pragma unroll 1   // (one row at a time: two interleaved rows would not fit the 128 registers of a 1024-thread workgroup)
-  for (int mm = m0 + w; mm < m_end; mm += S) pyz_head_row<UT, NP, true>(a.h, batch, ctl.row_off, p, mm, l);
+  pyz_head_row<UT, NP>(g, batch, ctl.row_off, p, m, l);
 }
 
 // ---------------------------------------------------------------- all weight gradients + update

@@ -24,8 +24,10 @@
 
 #define PYZ_HF_MAXI 8
 #define PYZ_HF_MAXC 8
+#ifndef PYZ_HF_THREADS
 #define PYZ_HF_THREADS 1024
 #define PYZ_HF_WAVES 16
+#endif
 
 struct HmcFusedArgs {
   float *q;                // (P, D) in/out
@@ -64,6 +66,11 @@ __device__ __forceinline__ double pyz_hf_block_sum(double v, double *sm) {
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < WAVES; ++i) s += sm[i];
+  // The total is pinned HERE: left alone, the compiler keeps the WAVES partials of an early call in registers
+  // and sinks their sum to the first use of the result -- for the energies of k_hmc_fused that is the
+  // Metropolis test at the very end, 32 registers per call held across the whole leapfrog loop (and spilled:
+  // .vgpr_spill_count 44-149 before this line, 0 after).
+  asm volatile("" : "+v"(s));
   return s;  // every thread gets the same total
 }
 
@@ -145,7 +152,7 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     }
 #pragma unroll
     for (int c = 0; c < MC; ++c) z0[c] = z1[c] = c < C ? b2[c] : 0.0f;
-#pragma unroll 2
+#pragma unroll(MI + MC > 8 ? 1 : 2)
     for (int j = 0; j < H; ++j) {
       const float *rec = wj + j * SJ;
       float h0 = rec[MI + MC], h1 = h0;
@@ -189,12 +196,15 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     }
     const float bj = rec[MI + MC];
     const int rb = (int)(((long long)N * w) / WAVES), re = (int)(((long long)N * (w + 1)) / WAVES);
-    // four rows per trip: their LDS reads are issued together and the four dependent
-    // chains (pre -> h -> dh -> dpre) interleave instead of serialising on LDS latency
-    for (int r = rb; r < re; r += 4) {
-      float xv[4][MI], dv[4][MC], dsel[4];
+    // RB rows per trip: their LDS reads are issued together and the dependent chains
+    // (pre -> h -> dh -> dpre) interleave instead of serialising on LDS latency (four rows; two for the
+    // widest instantiation, whose 4 x (MI + MC) staged operands do not fit the 128 registers of a 1024-thread
+    // workgroup)
+    constexpr int RB = (MI + MC > 8) ? 2 : 4;
+    for (int r = rb; r < re; r += RB) {
+      float xv[RB][MI], dv[RB][MC], dsel[RB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RB; ++u) {
         const int rr = min(r + u, re - 1);
 #pragma unroll
         for (int i = 0; i < MI; ++i) xv[u][i] = xs[rr * MI + i];
@@ -203,7 +213,7 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
         dsel[u] = d2[rr * MC + cbc];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RB; ++u) {
         const float on = (r + u < re) ? 1.0f : 0.0f;  // rows past the slice contribute nothing
         float pre = bj, dh = 0.0f;
 #pragma unroll

@@ -234,9 +234,10 @@ def bench_sgld(args, rank, world, backend, dev):
         per = kp.by_kernel()
         # algorithmic FLOP per launch: forward of layer 0 = 2 B (K+1) N; head = last layer forward
         # + its data gradient; k_wgrad_all = [dW; db] of both layers
-        flop_of = {"k_dense_fwd": 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1],
-                   "k_head_rows": 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2] + 2.0 * BATCH * DIMS[1] * DIMS[2],
-                   "k_wgrad_all": 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1] + 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]}
+        f_fwd = 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1]
+        f_head = 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2] + 2.0 * BATCH * DIMS[1] * DIMS[2]
+        flop_of = {"k_dense_fwd": f_fwd, "k_head_rows": f_head,
+                   "k_wgrad_all": f_fwd + 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]}
         kern = {}
         for name, (count, us) in per.items():
             base = name.split("<")[0]

@@ -363,40 +363,3 @@ def test_svgd_median_heuristic_kernel(eng, monkeypatch, M, gram):
         plan.svgd_step(p, p, 0, am, av, xd, yd, lr, "median", 3, loss, sweep="gauss_seidel")
     plan.close()
 
-
-# ------------------------------------------------------------------ fused last-hidden-layer + head launch
-def test_fused_forward_head_handoff_is_bitwise_the_two_launch_path(eng, monkeypatch):
-    """k_fwd_head hands the hidden activations from the workgroups that computed them to the workgroup that
-    finishes the row block INSIDE one launch (sc1 stores, arrival counter, sc1 loads).  A stale read would not
-    fault, it would use the previous launch's activations: two very different parameter vectors are alternated
-    (so that every launch overwrites every activation with a different value) for 150 launches each at the C2
-    shape, batch 1024 and the ragged 896, and every loss / gradient must equal, bit for bit, what the
-    two-launch path (PYZ_FUSE_HEAD=0: same arithmetic, kernel boundary instead of the hand-off) gives."""
-    spec = MNIST
-    x, y = synth.mnist_like(4096)
-    rng = np.random.default_rng(9)
-    ta = synth.glorot_uniform(spec.dims)
-    tb = (-1.7 * ta + 0.05 * rng.normal(size=ta.shape)).astype(np.float32)
-    xd, yd = dev(x), dev(y, torch.int32)
-    plan = eng.MLPPlan(espec(eng, spec), max_batch=1024)
-    idx = {b: dev(rng.permutation(4096)[:b].astype(np.int32), torch.int32) for b in (1024, 896)}
-    thetas = {"a": dev(ta), "b": dev(tb)}
-    monkeypatch.setenv("PYZ_FUSE_HEAD", "0")
-    ref = {}
-    for k, th in thetas.items():
-        for b in (1024, 896):
-            loss, grad = plan.loss_grad(th, xd, yd, batch=b, row_idx=idx[b])
-            ref[k, b] = (loss.clone(), grad.clone())
-    assert not torch.equal(ref["a", 1024][1], ref["b", 1024][1])
-    monkeypatch.setenv("PYZ_FUSE_HEAD", "1")
-    with eng.KernelProbe(16) as kp:
-        plan.loss_grad(thetas["a"], xd, yd, batch=1024, row_idx=idx[1024])
-    assert any(name.startswith("k_fwd_head") for name, _ in kp.launches), kp.launches      # the fused launch is what runs
-    bad = 0
-    for it in range(150):
-        for k in ("a", "b"):
-            b = 896 if (it % 3 == 2) else 1024
-            loss, grad = plan.loss_grad(thetas[k], xd, yd, batch=b, row_idx=idx[b])
-            bad += int(not (torch.equal(loss, ref[k, b][0]) and torch.equal(grad, ref[k, b][1])))
-    assert bad == 0, f"{bad} of 300 fused launches differ from the two-launch path"
-    plan.close()

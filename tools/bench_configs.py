@@ -67,27 +67,35 @@ def main():
         print(json.dumps({"config": "C4 BBB 784->400->400->10 B=1024", "us_per_step": round(us, 2), "steps_per_s": round(1e6 / us, 1),
                           "tflops": round(2292e6 / us / 1e6, 2), "validation_forward_us": round(usv, 2),
                           "steps_per_s_with_reference_validation": round(1e6 / (us + 0.9 * usv), 1), "cost": float(cost[0])}))
-    if "c3" in only:   # HMC moons 2->50->2, L=20
+    if "c3" in only:   # HMC moons 2->50->2, L=20, epsilon 0.005, m 0.5 (HMC_classification.py:135-136)
         xm, ym = synth.moons(2000)
         xm, ym = xm[:1600], ym[:1600]
         spec = engine.MLPSpec((2, 50, 2), ("relu", "softmax"), "scce")
         for chains in (1, 8, 64):
             plan = engine.MLPPlan(spec, max_batch=1600, max_particles=chains)
-            q = torch.zeros((chains, spec.n_params), device=dev)
+            q = torch.zeros((chains, spec.n_params), device=dev)          # HMC.py:69-72: q <- prior mean
             stats = torch.zeros((chains, 8), device=dev)
             xd, yd = torch.as_tensor(xm).to(dev), torch.as_tensor(ym).to(dev)
-            k = [0]
+            k, acc = [0], []
 
-            def step():
+            def step(burning=False):
                 k[0] += 1
-                plan.hmc_step(q, xd, yd, 20, 0.002, 0.5, 0.0, 1.0, np.random.default_rng(k[0]).random(chains), k[0], 7, stats)
+                plan.hmc_step(q, xd, yd, 20, 0.005, 0.5, 0.0, 1.0, np.random.default_rng(k[0]).random(chains), k[0], 7, stats,
+                              burning=burning)
+                if not burning:
+                    acc.append(stats[:, 0].clone())
             side = torch.cuda.Stream()       # a stream that can be captured (sliced proposals replay a hipGraph)
             torch.cuda.synchronize()
             with torch.cuda.stream(side):
+                for _ in range(10):          # HMC.train's 10 forced burn-in proposals (HMC.py:111-116): the chain leaves q = 0
+                    step(burning=True)
                 us = timed(step, 50)
-            print(json.dumps({"config": "C3 HMC moons 2->50->2 L=20 N=1600", "chains_on_gpu": chains, "us_per_sample": round(us, 1),
-                              "samples_per_s_per_chain": round(1e6 / us, 1), "samples_per_s_aggregate": round(chains * 1e6 / us, 1),
-                              "grad_evals_per_s": round(chains * 21 * 1e6 / us, 1), "accept_rate_last": float(stats[:, 0].mean())}))
+            rate = float(torch.stack(acc[3:]).mean())     # (timed() warms up with 3 proposals)
+            print(json.dumps({"config": "C3 HMC moons 2->50->2 L=20 N=1600 eps=0.005 m=0.5 prior (0, 1)", "chains_on_gpu": chains,
+                              "us_per_sample": round(us, 1), "samples_per_s_per_chain": round(1e6 / us, 1),
+                              "samples_per_s_aggregate": round(chains * 1e6 / us, 1),
+                              "grad_evals_per_s": round(chains * 21 * 1e6 / us, 1), "accept_rate_timed": round(rate, 3),
+                              "kernel_path": os.environ.get("PYZ_HMC_MULTI", "1") == "1" and chains <= 16 and "k_hmc_multi" or "k_hmc_fused"}))
     if "c5" in only:   # SVGD 64 particles 784->200->10
         dims = (784, 200, 10)
         spec = engine.MLPSpec(dims, ("relu", "softmax"), "scce")
