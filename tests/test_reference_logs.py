@@ -90,6 +90,19 @@ def test_oracle_reproduces_hmc_log_rows_under_the_nan_potential():
     assert one["accepted"] == 0 and one["distinct_samples"] == 1      # Appendix A2: only the burn-in moved q
 
 
+def test_committed_27_row_analysis_favours_the_nan_potential_reading():
+    """tests/golden/hmc_log_hypotheses.json is the output of tools/hmc_log_hypotheses.py (all 27 rows x 3 seeds x the two
+    readings of GaussianPrior(0.0, -1.0), ~20 CPU-minutes with the oracle; not recomputed here).  Appendix A2 (NaN
+    potential: nothing accepted after the burn-in) is unbiased against the log (mean signed deviation within 2
+    points), the validated-scale reading overshoots it by more than 3 points on average, and most rows sit
+    closer to A2."""
+    import json
+    s = json.load(open(os.path.join(ROOT, "tests", "golden", "hmc_log_hypotheses.json")))["summary"]
+    assert s["rows"] == 27 and s["seeds"] >= 3
+    assert abs(s["mean_signed_log_minus_A2"]) < 2.0 and s["mean_signed_log_minus_valid"] < -3.0
+    assert s["mean_abs_dev_log_vs_A2"] < s["mean_abs_dev_log_vs_valid"] and s["rows_where_log_is_closer_to_A2"] >= 15
+
+
 # ------------------------------------------------------------------ GPU: the drop-in surface against the logs
 @pytest.mark.gpu
 def test_gpu_surface_reproduces_the_bbb_log_bands(gpu_device):
