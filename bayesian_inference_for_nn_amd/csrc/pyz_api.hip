@@ -238,52 +238,10 @@ void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, 
 // ---- fused path (pyz_fused.h): usable when the last layer fits one 32-wide tile
 inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
 
-// lane-resident operand shape of k_head_rows for a last layer K -> N (UT units x NP classes per lane); UT = 0: too wide
-inline void head_rows_shape(int K, int N, int *UT, int *NP) {
-  *UT = K <= 64 ? 1 : K <= 256 ? 4 : K <= 512 ? 8 : K <= 1024 ? 16 : 0;
-  *NP = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : N <= 16 ? 16 : N <= 24 ? 24 : 32;
-}
-inline bool head_rows_applies(int K, int N) {
-  int UT, NP;
-  head_rows_shape(K, N, &UT, &NP);
-  return pyz_env_int("PYZ_HEAD_ROWS", 1) && UT && UT * NP <= 128;
-}
-
-// The last hidden layer with its reduction split over workgroups (k_dense_fwd_split); returns the number of slices
-// the head has to add up, 0 when the form does not apply (nothing launched).
-int launch_forward_split(pyz_mlp *m, const DenseArgs &fg, int P, int grid_batch, hipStream_t st) {
-  if (!pyz_env_int("PYZ_FWD_SPLIT", 1)) return 0;   // read per call: tests flip it
-  if (P != 1 || !m->fsplit || grid_batch < 128) return 0;
-  if (fg.K % 4 != 0 || fg.lda % 4 != 0 || !aligned16(fg.in) || fg.N % 2 != 0 || fg.w_off % 2 != 0 ||
-      (reinterpret_cast<uintptr_t>(fg.theta) & 7) != 0 || (fg.gather_out && !aligned16(fg.gather_out)))
-    return 0;
-  if (!head_rows_applies(fg.N, m->dims[m->L])) return 0;   // the MFMA head takes a finished input only
-  const int rbs = cdiv(grid_batch, 64), cbs = cdiv(fg.N, 64);
-  const int tiles = rbs * cbs;
-  const int splits = std::min(PYZ_FSPLIT_MAX, (256 + tiles / 2) / tiles);
-  if (splits < 2) return 0;
-  DenseSplitArgs a{};
-  a.d = fg;
-  a.partial = m->fsplit;
-  a.split_stride = (long long)m->max_batch * fg.N;
-  a.splits = splits;
-  a.kc = (cdiv(fg.K, splits) + 3) / 4 * 4;
-  PYZ_LAUNCH(k_dense_fwd_split, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a);
-  return splits;
-}
-
 void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
-                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st,
-                 int hsplits = 0) {
+                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st) {
   const int l = m->L - 1;
   HeadArgs g{};
-  if (hsplits > 0) {   // the input arrives as slices of the previous layer's reduction
-    g.hpart = m->fsplit;
-    g.hsplits = hsplits;
-    g.hsplit_stride = (long long)m->max_batch * m->dims[l];
-    g.hbias = theta + m->w_off[l - 1] + (long long)m->dims[l - 1] * m->dims[l];
-    g.hstore = m->act[l - 1];
-  }
   g.K = m->dims[l];
   g.N = m->dims[l + 1];
   if (l == 0) {
@@ -318,9 +276,10 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
     m->pend_on = false;
   }
   // one wave per batch row when the lane-resident operands fit (UT units x NP classes per lane)
-  int UT, NP;
-  head_rows_shape(g.K, g.N, &UT, &NP);
-  if (head_rows_applies(g.K, g.N)) {
+  static const int rows_on = pyz_env_int("PYZ_HEAD_ROWS", 1);
+  const int UT = g.K <= 64 ? 1 : g.K <= 256 ? 4 : g.K <= 512 ? 8 : g.K <= 1024 ? 16 : 0;
+  const int NP = g.N <= 4 ? 4 : g.N <= 8 ? 8 : g.N <= 12 ? 12 : g.N <= 16 ? 16 : g.N <= 24 ? 24 : 32;
+  if (rows_on && UT && UT * NP <= 128) {
     g.nblk = grid_batch;  // one loss partial per row
     m->cur_nblk = g.nblk;
     const dim3 grid((unsigned)cdiv(grid_batch, 4), P), block(256);
@@ -414,16 +373,8 @@ void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, in
   if (can_fuse(m)) {
     static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 1);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
-    // hidden layers, then the head.  Single chain: the last hidden layer leaves slices of its reduction and the
-    // head adds them up (k_dense_fwd_split); else every layer finishes its own output.
-    int hsplits = 0;
-    if (m->L >= 2) {
-      launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb, m->L - 2);
-      const DenseArgs fg = forward_args(m, m->L - 2, theta, theta_ps, x, row_idx, ctl, xb);
-      hsplits = launch_forward_split(m, fg, P, grid_batch, st);
-      if (!hsplits) pyz_launch_fwd(fg, grid_batch, P, st);
-    }
-    launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st, hsplits);
+    launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb, m->L - 1);   // hidden layers
+    launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);
     if (want_grad) {
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
       launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xb);
@@ -519,13 +470,6 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   }
   if (hipMalloc((void **)&m->nonfinite, 64) != hipSuccess || hipMemset(m->nonfinite, 0, 64) != hipSuccess)
     return fail(pyz_fail(PYZ_E_OOM, "counter allocation failed"));
-  if (max_particles == 1 && n_layers >= 2) {  // single chain: the last hidden layer may run with its reduction split
-    const size_t bytes = sizeof(float) * (size_t)PYZ_FSPLIT_MAX * max_batch * m->dims[n_layers - 1] + 64;
-    if (bytes <= ((size_t)512 << 20)) {
-      if (hipMalloc((void **)&m->fsplit, bytes) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
-      m->ws_bytes += bytes;
-    }
-  }
   if (hipMalloc((void **)&m->ctl, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "ctl allocation failed"));
   if (hipMemset(m->ctl, 0, 2 * sizeof(StepCtl)) != hipSuccess) return fail(pyz_fail(PYZ_E_HIP, "ctl memset failed"));
   const size_t scal = sizeof(float) * (size_t)(max_particles * 16 + 64);
@@ -549,7 +493,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite, m->fsplit};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) {

@@ -140,7 +140,6 @@ inline PyzProbe &pyz_probe() {
   } while (0)
 
 // ---------------------------------------------------------------- the plan
-#define PYZ_FSPLIT_MAX 4     // slices of the last hidden layer's reduction (k_dense_fwd_split)
 #define PYZ_GRAPH_CHUNKS 8  // captured step graphs of G, then 2^k < G, ..., 2, 1 steps
 struct pyz_mlp {
   int L = 0;
@@ -177,5 +176,4 @@ struct pyz_mlp {
   // what the last pyz_*_run call did: steps inside replayed graphs, eager steps, graph launches
   int run_graph_steps = 0, run_eager_steps = 0, run_graph_launches = 0;
   int *nonfinite = nullptr;                  // device counter: steps whose loss was NaN / Inf (pyz_check_finite)
-  float *fsplit = nullptr;                   // (PYZ_FSPLIT_MAX, max_batch, dims[L-1]) partial sums of k_dense_fwd_split
 };

@@ -41,13 +41,6 @@ struct HeadArgs {
   const StepCtl *ctl;
   StepCtl init;              // the step scalars by value when the head is the first kernel of an eager step (L == 1)
   int init_on;
-  // input left as partial sums by k_dense_fwd_split (k_head_rows only): hin row = act_prev(bias + sum over the
-  // slices, in slice order); the finished row is also stored to hstore (the weight-gradient kernel reads it)
-  const float *hpart;        // (hsplits, max_batch, K) or nullptr: hin holds the finished input
-  long long hsplit_stride;
-  int hsplits;
-  const float *hbias;        // (K) bias of the layer that produced the partial sums
-  float *hstore;             // (max_batch, K)
 };
 
 // lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
@@ -295,15 +288,7 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
 #pragma unroll
   for (int t = 0; t < UT; ++t) {
     const int u = l + 64 * t;
-    if (g.hpart) {   // wave-uniform: the previous layer left slices of its reduction (k_dense_fwd_split)
-      float sum = u < K ? g.hbias[u] : 0.0f;
-      for (int sp = 0; sp < g.hsplits; ++sp)
-        sum += u < K ? g.hpart[sp * g.hsplit_stride + (long long)m * K + u] : 0.0f;
-      hv[t] = pyz_act(sum, g.act_prev);
-      if (u < K) g.hstore[(long long)m * K + u] = hv[t];
-    } else {
-      hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
-    }
+    hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
     // only the per-lane offset is range checked by the hardware (not the scalar one): units past K get an
     // out-of-range voffset; a padded class c >= N reads a neighbouring in-range element (or 0 past the
     // end), which is harmless: z[c] is never used and delta_L[c] = 0 multiplies it below

@@ -428,111 +428,6 @@ __global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
   }
 }
 
-// ---------------------------------------------------------------- forward of the last hidden layer, reduction split
-// over workgroups (single chain).  What bounds k_dense_fwd on a single chain is not the matrix pipe but the
-// operand bytes each CU pulls through its L1: a 32 x 32 tile over the whole reduction is (32 + 32) K floats =
-// 200 KB per CU at 784 -> 200, at the 40 - 70 GB/s one CU gets from L2 / the Infinity Cache.  Here a workgroup
-// owns a 64 x 64 tile over a SLICE of K (kc values): (64 + 64) kc floats = 100 KB for the same 392 matrix
-// instructions per CU, and the grid (row blocks x column blocks x slices) covers all 256 CUs.  The partial sums
-// go to `partial` (slices, max_batch, N) and are NOT combined by another launch: the consumer is the head
-// kernel, which adds the slices of its row in a fixed order together with the bias, applies the activation and
-// leaves the layer output for the weight-gradient kernel (pyz_head_row).
-// Four waves, one 32 x 32 sub-tile each (2 x 2); 32-deep slabs of both operands staged in LDS, the next slab
-// travelling global -> registers while the current one feeds the matrix instructions.  Needs K % 4 == 0 with
-// 16-byte aligned input rows and an even N with 8-byte aligned [W; b] blocks (checked at launch).
-struct DenseSplitArgs {
-  DenseArgs d;       // d.out unused; d.gather_out as in k_dense_fwd (written by the column-block-0 workgroups)
-  float *partial;    // (splits, max_batch, N) partial sums, no bias, no activation
-  long long split_stride;  // max_batch * N
-  int splits, kc;    // slices of the reduction and their length (a multiple of 4)
-};
-
-__global__ void __launch_bounds__(256) k_dense_fwd_split(DenseSplitArgs a) {
-  constexpr int BM = 64, BN = 64, BK = 32, AS = BM + 32, BS = BN + 32;   // (+32: the two reduction halves of a
-                                                                          //  fragment sit 32 banks apart)
-  __shared__ __attribute__((aligned(16))) float As[2][BK][AS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BS];
-  const DenseArgs &g = a.d;
-  const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63, r = l & 31, h = l >> 5;
-  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
-  const int batch = ctl.batch;
-  const int K = g.K, N = g.N;
-  const int cbs = (N + BN - 1) / BN;
-  const int rbs_grid = (int)gridDim.x / (cbs * a.splits);      // row blocks the launch was sized for
-  const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
-  if (tile >= rbs_grid * cbs * a.splits) return;               // (a grid that is not a whole number of row blocks)
-  // consecutive ids share (slice, row block): the column blocks that read the same input rows sit on one XCD
-  const int cb = tile % cbs, rb = (tile / cbs) % rbs_grid, sp = tile / (cbs * rbs_grid);
-  const int m0 = rb * BM, n0 = cb * BN;
-  if (m0 >= batch) return;  // uniform
-  const int k_begin = sp * a.kc, k_end = min(K, k_begin + a.kc);
-  // staging assignment.  A: four lanes per row (64 contiguous bytes of the row per slab half), B: float2 pieces
-  const int ra = t >> 2, kq = 4 * (t & 3);
-  const int ma = min(m0 + ra, batch - 1);
-  long long rowa = ma;
-  if (g.row_idx) rowa = g.row_idx[ctl.row_off + ma];
-  const float *ap = g.in + rowa * g.lda;
-  const float *wl = g.theta + g.w_off;
-  float *gp = (g.gather_out && cb == 0 && m0 + ra < batch) ? g.gather_out + (long long)ma * K : nullptr;
-  float4 va[2];
-  float2 vb[4];
-  auto fetch = [&](const int k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + kq + 16 * j;
-      va[j] = k < k_end ? *reinterpret_cast<const float4 *>(ap + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = t + 256 * j, kr = idx >> 5, c2 = idx & 31;
-      const int k = k0 + kr, n = n0 + 2 * c2;
-      vb[j] = (k < k_end && n < N) ? *reinterpret_cast<const float2 *>(wl + (long long)k * N + n) : make_float2(0.f, 0.f);
-    }
-  };
-  auto stage = [&](const int buf, const int k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kk = kq + 16 * j;
-      As[buf][kk + 0][ra] = va[j].x;
-      As[buf][kk + 1][ra] = va[j].y;
-      As[buf][kk + 2][ra] = va[j].z;
-      As[buf][kk + 3][ra] = va[j].w;
-      if (gp && k0 + kk < k_end) *reinterpret_cast<float4 *>(gp + k0 + kk) = va[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = t + 256 * j, kr = idx >> 5, c2 = idx & 31;
-      *reinterpret_cast<float2 *>(&Bs[buf][kr][2 * c2]) = vb[j];
-    }
-  };
-  const int rh = w & 1, ch = w >> 1;   // this wave's sub-tile
-  f32x16 acc = {0};
-  const int ns = (k_end - k_begin + BK - 1) / BK;
-  if (ns > 0) {
-    fetch(k_begin);
-    stage(0, k_begin);
-  }
-  __syncthreads();
-  for (int s = 0; s < ns; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < ns) fetch(k_begin + (s + 1) * BK);
-#pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp)
-      acc = pyz_mfma(As[buf][2 * kp + h][32 * rh + r], Bs[buf][2 * kp + h][32 * ch + r], acc);
-    if (s + 1 < ns) stage(buf ^ 1, k_begin + (s + 1) * BK);
-    __syncthreads();
-  }
-  float *op = a.partial + (long long)sp * a.split_stride;
-  const int nn = n0 + 32 * ch + r;
-  if (nn < N) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int mm = m0 + 32 * rh + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (mm < batch) op[(long long)mm * N + nn] = acc[i];
-    }
-  }
-}
-
 // ---------------------------------------------------------------- data gradient
 // out[p][m][j] = ( sum_n delta[p][m][n] * W[j][n] ) * act'(hprev[p][m][j]),  j < K.
 // `in` = delta (row stride N), `aux` = previous layer's output (row stride K).

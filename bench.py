@@ -236,7 +236,7 @@ def bench_sgld(args, rank, world, backend, dev):
         # + its data gradient; k_wgrad_all = [dW; db] of both layers
         f_fwd = 2.0 * BATCH * (DIMS[0] + 1) * DIMS[1]
         f_head = 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2] + 2.0 * BATCH * DIMS[1] * DIMS[2]
-        flop_of = {"k_dense_fwd": f_fwd, "k_dense_fwd_split": f_fwd, "k_head_rows": f_head,
+        flop_of = {"k_dense_fwd": f_fwd, "k_head_rows": f_head,
                    "k_wgrad_all": f_fwd + 2.0 * BATCH * (DIMS[1] + 1) * DIMS[2]}
         kern = {}
         for name, (count, us) in per.items():
