@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; `bench.py --no-roofline`) into
-profiles/r01_pmc_traffic.json: HBM bytes per launch of each kernel of the SGLD step.
+profiles/r02_pmc_traffic.json: HBM bytes per launch of each kernel of the SGLD step.
 Units and corrections per MI355X_MICROARCH.md (section HBM): both counters are in KB; on gfx950
 FETCH_SIZE reports half the bytes of a WIDE (16 B/lane) coalesced stream and is uncalibrated for
 other widths, so it is calibrated here on a known byte count in our own access pattern:
@@ -23,7 +23,7 @@ def agg(pattern, counter):
     for path in glob.glob(pattern):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
-                name = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+                name = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].strip()
                 d[name].append(float(r["Counter_Value"]))
     return d
 
@@ -46,7 +46,7 @@ def main():
             out["kernels"][k] = {"launches": len(f[k]), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
                                  "hbm_bytes_per_launch": int((fk + wk) * 1024),
                                  "hbm_bytes_upper_bound": int((2 * fk + wk) * 1024)}
-    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
