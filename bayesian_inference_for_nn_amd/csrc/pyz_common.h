@@ -140,7 +140,7 @@ inline PyzProbe &pyz_probe() {
   } while (0)
 
 // ---------------------------------------------------------------- the plan
-#define PYZ_GRAPH_CHUNKS 8  // captured step graphs of G, then 2^k < G, ..., 2, 1 steps
+#define PYZ_GRAPH_CHUNKS 8  // captured step graphs: slot 0 = G steps, the others = remainders by exact length (LRU)
 struct pyz_mlp {
   int L = 0;
   int dims[PYZ_MAX_LAYERS + 1] = {0};
@@ -172,6 +172,7 @@ struct pyz_mlp {
   hipGraph_t graph[PYZ_GRAPH_CHUNKS] = {nullptr};
   hipGraphExec_t graph_exec[PYZ_GRAPH_CHUNKS] = {nullptr};
   int graph_len[PYZ_GRAPH_CHUNKS] = {0};
+  unsigned long long graph_use[PYZ_GRAPH_CHUNKS] = {0}, graph_clock = 0;   // last use of a slot (eviction order)
   unsigned long long graph_key = 0;
   // what the last pyz_*_run call did: steps inside replayed graphs, eager steps, graph launches
   int run_graph_steps = 0, run_eager_steps = 0, run_graph_launches = 0;

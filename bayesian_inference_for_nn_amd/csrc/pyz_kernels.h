@@ -70,6 +70,31 @@ __global__ void k_set_ctl(StepCtl *ctl, int batch, float lr, long long n, long l
   ctl->slot0 = slot0;
 }
 
+// Short device-resident runs (at most PYZ_INLINE_TAB steps): the per-run tables travel as kernel arguments and
+// this one launch writes them and the first step's scalars -- no host-to-device copy in front of the first step.
+#define PYZ_INLINE_TAB 32
+struct InlineTabs {
+  int32_t bs[PYZ_INLINE_TAB + 1];
+  float lr[PYZ_INLINE_TAB + 1];
+  int n;   // entries (steps + the padding entry)
+};
+__global__ void k_set_ctl_tabs(StepCtl *ctl, InlineTabs t, int32_t *tab_bs, float *tab_lr, long long n, long long row_off,
+                               int slot0) {
+  const int e = threadIdx.x;
+  if (e < t.n) {
+    tab_bs[e] = t.bs[e];
+    tab_lr[e] = t.lr[e];
+  }
+  if (e == 0) {
+    ctl->batch = t.bs[0];
+    ctl->lr = t.lr[0];
+    ctl->n = n;
+    ctl->row_off = row_off;
+    ctl->i = 0;
+    ctl->slot0 = slot0;
+  }
+}
+
 // The last kernel of a step prepares the OTHER StepCtl slot for the next step
 // (ping-pong: nobody reads that slot during this step).
 __device__ __forceinline__ void pyz_prepare_next(const StepCtl *ctl, StepCtl *next, const int32_t *tab_bs,

@@ -150,7 +150,8 @@ int pyz_swag_run(pyz_mlp *mlp, float *d_theta, float *d_mean, float *d_sq_mean, 
 
 /* What the last pyz_sgld_run / pyz_sgd_run / pyz_swag_run call on this plan did: steps that ran inside replayed
  * hipGraphs, steps launched eagerly, and the number of graph launches.  With use_graph != 0 on a non-NULL
- * stream a run of any length is replayed from graphs of 32, 16, 8, 4, 2 and 1 steps (PYZ_GRAPH_STEPS = 32). */
+ * stream a run of any length is replayed from graphs: chunks of 32 steps (PYZ_GRAPH_STEPS) and one graph for
+ * the remainder, captured for its exact length and kept (seven lengths, least recently used one replaced). */
 int pyz_last_run_info(const pyz_mlp *mlp, int32_t *h_graph_steps, int32_t *h_eager_steps,
                       int32_t *h_graph_launches);
 

@@ -112,8 +112,8 @@ def test_c2_sgld_single_steps_full_shape(eng):
 @pytest.mark.parametrize("n_steps", [70, 20])
 def test_c2_sgld_graph_run_full_shape(eng, n_steps):
     """pyz_sgld_run(use_graph=1) at the bench shape: 2 944 rows -> batches 1024, 1024, 896 per epoch.  70 steps =
-    two replays of the 32-step graph + a 6-step remainder; 20 steps = shorter than one graph (the driver's
-    bench invocation): the remainder is replayed as a graph of its own."""
+    two replays of the 32-step graph + a 6-step remainder graph; 20 steps = shorter than one chunk (the driver's
+    bench invocation): one graph of exactly 20 steps, its tables carried by the launch that sets the scalars."""
     n_rows = 2944
     x, y, theta0 = _c2_data(n_rows)
     D = MNIST.n_params
@@ -140,6 +140,7 @@ def test_c2_sgld_graph_run_full_shape(eng, n_steps):
     close(mean, st.mean, what="mean")
     close(sq, st.sq_mean, what="sq_mean")
     assert plan.last_run_path() == ("graph", n_steps)       # every step ran inside a replayed graph
+    assert plan.last_run_graph_launches() == (3 if n_steps == 70 else 1)
     plan.close()
 
 
