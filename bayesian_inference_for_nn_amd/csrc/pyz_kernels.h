@@ -994,6 +994,7 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
   double xj[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) xj[j] = j < g.M ? (double)xf[j] : 0.0;
+  const double two_gamma = 2.0 * (gamma_dev ? gamma_dev[0] : (double)g.gamma);
   for (int il = 0; il < g.n_local; ++il) {
     const int i = g.row0 + il;
     const double *kr = kmat + il * 64;
@@ -1010,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
       k4[j & 3] += kr[j];          // (wave-uniform: scalar-side work)
     }
     double rep = xid * ((k4[0] + k4[1]) + (k4[2] + k4[3])) - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
-    rep *= 2.0 * (gamma_dev ? gamma_dev[0] : (double)g.gamma);
+    rep *= two_gamma;
     const long long o = (long long)il * g.D + d;
     const float phi = (ksum[il] * g.grad[o] + (float)rep) / (float)g.M;
     float m = g.adam_m[o], v = g.adam_v[o];

@@ -64,6 +64,9 @@ def main():
         xv = x[:6000].contiguous()
         yv = y[:6000].contiguous()
         usv = timed(lambda: vplan.loss_grad(w, xv, yv, want_grad=False), 100)
+        with engine.KernelProbe(64) as kp:        # one step, every kernel with its own begin / end timestamps
+            step()
+        print(json.dumps({"config": "C4 BBB 784->400->400->10 B=1024", "kernels_us": [(n, round(v, 2)) for n, v in kp.launches]}))
         print(json.dumps({"config": "C4 BBB 784->400->400->10 B=1024", "us_per_step": round(us, 2), "steps_per_s": round(1e6 / us, 1),
                           "tflops": round(2292e6 / us / 1e6, 2), "validation_forward_us": round(usv, 2),
                           "steps_per_s_with_reference_validation": round(1e6 / (us + 0.9 * usv), 1), "cost": float(cost[0])}))
@@ -118,6 +121,14 @@ def main():
                 snap = p.clone() if sweep == "jacobi" else p
                 plan.svgd_step(p, snap, 0, am, av, x, y, 0.01, 1.0, k[0], loss, sweep=sweep, batch=sizes[s], row_idx=idx[s])
             us = timed(step, 20)
+            with engine.KernelProbe(256) as kp:
+                step()
+            agg = {}
+            for n, v in kp.launches:
+                c, t = agg.get(n, (0, 0.0))
+                agg[n] = (c + 1, t + v)
+            print(json.dumps({"config": "C5 SVGD M=64 784->200->10 B=1024 1 GPU", "sweep": sweep, "init_scale": scale,
+                              "kernels_us_total": {n: [c, round(t, 1)] for n, (c, t) in agg.items()}}))
             print(json.dumps({"config": "C5 SVGD M=64 784->200->10 B=1024 1 GPU", "sweep": sweep, "init_scale": scale,
                               "us_per_step": round(us, 1), "svgd_steps_per_s": round(1e6 / us, 2),
                               "particle_grad_steps_per_s": round(M * 1e6 / us, 1), "tflops": round(45.2e9 / us / 1e6, 2),
