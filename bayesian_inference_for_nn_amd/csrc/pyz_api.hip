@@ -358,7 +358,10 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
   const dim3 grid(pyz_pad8((long long)tiles + 1, P), P);  // + the duties workgroup (+ padding, see pyz_pad8)
   switch (S) {
-    case 1: PYZ_LAUNCH(k_wgrad_all<1>, grid, dim3(64), 0, st, a); break;
+    case 1:
+      if (a.mode == PYZ_UPD_NONE) PYZ_LAUNCH((k_wgrad_all<1, true>), grid, dim3(64), 0, st, a);
+      else PYZ_LAUNCH(k_wgrad_all<1>, grid, dim3(64), 0, st, a);
+      break;
     case 2: PYZ_LAUNCH(k_wgrad_all<2>, grid, dim3(128), 2 * 4096, st, a); break;
     case 4: PYZ_LAUNCH(k_wgrad_all<4>, grid, dim3(256), 4 * 4096, st, a); break;
     case 8: PYZ_LAUNCH(k_wgrad_all<8>, grid, dim3(512), 8 * 4096, st, a); break;

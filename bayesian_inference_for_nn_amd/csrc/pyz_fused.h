@@ -606,8 +606,11 @@ __device__ __forceinline__ void pyz_wgrad_accumulate(f32x16 &acc, const float *a
   }
 }
 
-// S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread)
-template <int S>
+// S = waves per workgroup (compile time: the epilogue prefetches 16/S elements per thread).
+// PLAIN: the launch only writes gradients (g.mode == PYZ_UPD_NONE: particle-batched passes of SVGD / HMC, loss_grad):
+// no optimizer state is fetched, so the four prefetch arrays of the epilogue do not exist -- for S = 1 that is 64
+// registers per lane, i.e. the difference between two and four resident waves per SIMD.
+template <int S, bool PLAIN = false>
 __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   extern __shared__ float red[];
   PYZ_STAMP(2, 0);
@@ -631,7 +634,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int i0 = (t / tiles_n) * 32, n0 = (t % tiles_n) * 32;
   const int p = blockIdx.y;
   const long long w_off = ly.w_off;
-  const int mode = g.mode;
+  const int mode = PLAIN ? PYZ_UPD_NONE : g.mode;
   const long long nstep = g.ctl->n;
   const float lr = g.ctl->lr;
 
@@ -640,7 +643,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   //    (the hook of the pipelined loop) and their latency hides behind the loads and MFMAs
   long long ee[EPT];
   bool ev[EPT];
-  float th0[EPT], mu0[EPT], sq0[EPT], zz[EPT];
+  float th0[PLAIN ? 1 : EPT], mu0[PLAIN ? 1 : EPT], sq0[PLAIN ? 1 : EPT], zz[PLAIN ? 1 : EPT];
   auto prefetch = [&]() {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -656,6 +659,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       const int ii = i0 + ro, nn = n0 + co;
       ev[q] = ii <= K && nn < N;
       ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
+      if (PLAIN) continue;
       th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
       if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
       if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB || mode == PYZ_UPD_SWAG) {
@@ -664,7 +668,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
         if (g.unit_noise && mode != PYZ_UPD_SWAG) zz[q] = g.unit_noise[ee[q]];
       }
     }
-    if ((mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
+    if (!PLAIN && (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
         const float4 nq = mode == PYZ_UPD_SGLD
@@ -736,6 +740,10 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     if (!ev[q]) continue;
+    if (PLAIN) {
+      g.grad[p * g.grad_pstride + ee[q]] = gv[q];
+      continue;
+    }
     pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q], zz[q], lr, nstep));
   }
   PYZ_STAMP(2, 3);

@@ -133,6 +133,39 @@ def main():
                               "us_per_step": round(us, 1), "svgd_steps_per_s": round(1e6 / us, 2),
                               "particle_grad_steps_per_s": round(M * 1e6 / us, 1), "tflops": round(45.2e9 / us / 1e6, 2),
                               "loss": float(loss)}))
+    if "c5shard" in only:   # ONE rank's share of the 8-way sharded SVGD step (no gather: compute only), on this one GPU
+        dims = (784, 200, 10)
+        spec = engine.MLPSpec(dims, ("relu", "softmax"), "scce")
+        M, D = 64, spec.n_params
+        x_h, y_h = synth.mnist_like(48000)
+        x, y = torch.as_tensor(x_h).to(dev), torch.as_tensor(y_h).to(dev)
+        idx_h, sizes = synth.batch_plan(48000, 1024, 16)
+        idx = torch.as_tensor(idx_h).to(dev)
+        loss = torch.zeros(1, device=dev)
+        for n_local in (8, 16, 32, 64):
+            plan = engine.MLPPlan(spec, max_batch=1024, max_particles=n_local)
+            allp = torch.empty((M, D), device=dev)
+            engine.fill_normal(allp, 1, _lib.STREAM_INIT, 0, 0.0, 1.0)
+            local = allp[:n_local].clone()
+            am, av = torch.zeros((n_local, D), device=dev), torch.zeros((n_local, D), device=dev)
+            k = [0]
+
+            def grad():
+                s = k[0] % 16
+                k[0] += 1
+                plan.svgd_gradients(local, x, y, batch=sizes[s], row_idx=idx[s])
+
+            def sweep():
+                plan.svgd_sweep(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss, sweep="jacobi")
+            grad()
+            us_g = timed(grad, 30)
+            us_s = timed(sweep, 30)
+            with engine.KernelProbe(64) as kp:
+                grad()
+                sweep()
+            print(json.dumps({"config": f"C5 SVGD one rank of {M // n_local}: {n_local} local particles of 64, B=1024 (compute only, no gather)",
+                              "gradients_us": round(us_g, 1), "sweep_us": round(us_s, 1),
+                              "kernels_us": [(n, round(v, 1)) for n, v in kp.launches]}))
 
 
 if __name__ == "__main__":
