@@ -33,7 +33,7 @@ struct StepCtl {
 // -DPYZ_STAMPS builds libpyz_stamps.so: wave 0 of the first 256 workgroups records
 // {s_memtime, s_memrealtime} at phase boundaries.  The shipped library has no stamps.
 #ifdef PYZ_STAMPS
-#define PYZ_STAMP_KERNELS 4
+#define PYZ_STAMP_KERNELS 6   // 0 forward, 1 head, 2 weight gradients, 3 k_svgd_gs, 4 k_svgd_gram_tile, 5 k_svgd_update_tile
 #define PYZ_STAMP_BLOCKS 256
 #define PYZ_STAMP_WAVES 16
 #define PYZ_STAMP_SLOTS 8

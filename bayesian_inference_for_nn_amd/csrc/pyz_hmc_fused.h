@@ -152,7 +152,8 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     }
 #pragma unroll
     for (int c = 0; c < MC; ++c) z0[c] = z1[c] = c < C ? b2[c] : 0.0f;
-#pragma unroll(MI + MC > 8 ? 1 : 2)
+    constexpr int UJ = (MI + MC > 8) ? 1 : 2;
+#pragma unroll UJ
     for (int j = 0; j < H; ++j) {
       const float *rec = wj + j * SJ;
       float h0 = rec[MI + MC], h1 = h0;

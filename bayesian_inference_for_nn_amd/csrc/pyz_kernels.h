@@ -813,52 +813,52 @@ __global__ void k_probe_mfma_f64(int *out) {  // out[0..255]: row of D[r] per la
 }
 
 __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
-  __shared__ double gbuf[4096];                                  // the 64 x 64 Gram at the end ...
-  float (*xs)[64] = reinterpret_cast<float (*)[64]>(gbuf);       // ... and the staged slab [element][particle] before
+  constexpr int RS = 65;   // row stride (floats) of the staged slab: odd, so that a wave's transposing writes spread over the banks
+  __shared__ double gbuf[(PYZ_SV_E * RS + 1) / 2];               // the 64 x 64 Gram at the end (4 096 doubles) ...
+  float *xs = reinterpret_cast<float *>(gbuf);                   // ... and the staged slab [element][particle] before
   const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;
   const long long base = (long long)blockIdx.x * g.range;
-  const bool vec_ok = (g.D % 4 == 0);
   pyz_f64x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = pyz_f64x4{0.0, 0.0, 0.0, 0.0};
-  // lane = particle: each lane brings 8 x 16 bytes of its row per slab (wave w: elements 32 w .. 32 w + 31);
-  // the next slab is requested before the matrix instructions of the current one
-  const float *row = g.all + (long long)min(l, g.M - 1) * g.D;
-  auto fetch = [&](const long long e0, float4 (&v)[8]) {
+  // Lanes run along the ELEMENTS (two consecutive ones per lane), the particles over the instructions: wave w brings
+  // particles w, w + 4, ... -- 512 contiguous bytes of one row per load, the access k_svgd_gs streams the matrix with.
+  // (Lane = particle, 64 rows 636 KB apart per instruction, read this slab at 1.4 TB/s and made the kernel 48 us
+  // for 11 us of matrix instructions.)  The next slab is requested before the matrix instructions of the current one.
+  const bool pair_ok = (g.D % 2 == 0) && ((reinterpret_cast<uintptr_t>(g.all) & 7) == 0);   // every row 8-byte aligned
+  auto fetch = [&](const long long e0, float2 (&v)[16]) {
+    const long long d = e0 + 2 * l;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const long long d = e0 + 32 * w + 4 * q;
-      if (l < g.M && vec_ok && d + 3 < g.D) {
-        v[q] = *reinterpret_cast<const float4 *>(row + d);
+    for (int u = 0; u < 16; ++u) {
+      const int j = w + 4 * u;   // wave-uniform
+      const float *p = g.all + (long long)min(j, g.M - 1) * g.D + d;
+      if (j < g.M && pair_ok && d + 1 < g.D) {
+        v[u] = *reinterpret_cast<const float2 *>(p);
       } else {
-        v[q].x = (l < g.M && d + 0 < g.D) ? row[d + 0] : 0.0f;
-        v[q].y = (l < g.M && d + 1 < g.D) ? row[d + 1] : 0.0f;
-        v[q].z = (l < g.M && d + 2 < g.D) ? row[d + 2] : 0.0f;
-        v[q].w = (l < g.M && d + 3 < g.D) ? row[d + 3] : 0.0f;
+        v[u].x = (j < g.M && d < g.D) ? p[0] : 0.0f;
+        v[u].y = (j < g.M && d + 1 < g.D) ? p[1] : 0.0f;
       }
     }
   };
   const int n_slabs = g.range / PYZ_SV_E;
-  float4 v[8];
+  float2 v[16];
+  PYZ_STAMP(4, 0);
   if (base < g.D) fetch(base, v);
   for (int ps = 0; ps < n_slabs; ++ps) {
     const long long e0 = base + (long long)ps * PYZ_SV_E;
     if (e0 >= g.D) break;  // uniform
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = 32 * w + 4 * q;
-      xs[e + 0][l] = v[q].x;
-      xs[e + 1][l] = v[q].y;
-      xs[e + 2][l] = v[q].z;
-      xs[e + 3][l] = v[q].w;
+    for (int u = 0; u < 16; ++u) {
+      xs[(2 * l) * RS + w + 4 * u] = v[u].x;
+      xs[(2 * l + 1) * RS + w + 4 * u] = v[u].y;
     }
     __syncthreads();
     if (ps + 1 < n_slabs && e0 + PYZ_SV_E < g.D) fetch(e0 + PYZ_SV_E, v);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const float *xe = xs[32 * w + 4 * ks + (l >> 4)];
+      const float *xe = xs + (32 * w + 4 * ks + (l >> 4)) * RS;
       double a[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) a[b] = (double)xe[(l & 15) + 16 * b];
@@ -868,8 +868,10 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
         for (int cb = rb; cb < 4; ++cb)   // G is symmetric bit for bit: the 10 blocks on and above the diagonal
           acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], a[cb], acc[rb][cb], 0, 0, 0);
     }
+    if (ps == 0) PYZ_STAMP(4, 1);
     __syncthreads();
   }
+  PYZ_STAMP(4, 2);
   // the four waves' partial Grams, added in wave order (the slab is dead: its storage holds G now)
   for (int ww = 0; ww < 4; ++ww) {
     if (w == ww) {
@@ -887,11 +889,13 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
     }
     __syncthreads();
   }
+  PYZ_STAMP(4, 3);
   for (int e = t; e < g.n_local * 64; e += 256) {
     const int il = e >> 6, j = e & 63;
     g.part[((long long)il * g.nblk + blockIdx.x) * 64 + j] = gbuf[(g.row0 + il) * 64 + j];
   }
   if (t < 64) g.diag[(long long)blockIdx.x * 64 + t] = gbuf[t * 64 + t];
+  PYZ_STAMP(4, 4);
 }
 
 // dist_only != 0: the squared distances of the row go to g.dmat and nothing else happens (first half of the

@@ -38,7 +38,7 @@ with torch.cuda.stream(st):
     for rep in range(3):
         plan.sgld_run(theta, mean, sq, x, y, idx, sizes, lrs, 0, 1, losses, use_graph=True)
 st.synchronize()
-K, B, W, S = 4, 256, 16, 8
+K, B, W, S = 6, 256, 16, 8
 buf = (C.c_uint64 * (K * B * W * S * 2))()
 _lib.check(_lib.load().pyz_debug_stamps(buf, K * B * W * S * 2))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)

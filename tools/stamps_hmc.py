@@ -23,7 +23,7 @@ xd, yd = torch.as_tensor(xm).cuda(), torch.as_tensor(ym).cuda()
 for k in range(5):
     plan.hmc_step(q, xd, yd, 20, 0.002, 0.5, 0.0, 1.0, [0.5] * 4, k, 7, stats)
 torch.cuda.synchronize()
-K, B, W, S = 4, 64, 16, 8
+K, B, W, S = 6, 256, 16, 8
 buf = (C.c_uint64 * (K * B * W * S * 2))()
 _lib.check(_lib.load().pyz_debug_stamps(buf, K * B * W * S * 2))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)
