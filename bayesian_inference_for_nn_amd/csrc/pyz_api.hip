@@ -282,9 +282,15 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   if (rows_on && UT && UT * NP <= 128) {
     g.nblk = grid_batch;  // one loss partial per row
     m->cur_nblk = g.nblk;
-    const dim3 grid((unsigned)cdiv(grid_batch, 4), P), block(256);
-#define PYZ_HEAD_ROWS_CASE(U, C) \
-  if (UT == U && NP == C) { PYZ_LAUNCH((k_head_rows<U, C>), grid, block, 0, st, g); return; }
+    // rows per wave: four when the launch has tens of thousands of rows (many particles), else one
+    const int RW = (long long)P * grid_batch >= 32768 ? 4 : 1;
+    const dim3 grid((unsigned)cdiv(cdiv(grid_batch, RW), 4), P), block(256);
+#define PYZ_HEAD_ROWS_CASE(U, C)                                                               \
+  if (UT == U && NP == C) {                                                                    \
+    if (RW == 4) PYZ_LAUNCH((k_head_rows<U, C, 4>), grid, block, 0, st, g);                     \
+    else PYZ_LAUNCH((k_head_rows<U, C, 1>), grid, block, 0, st, g);                            \
+    return;                                                                                    \
+  }
     PYZ_HEAD_ROWS_CASE(1, 4) PYZ_HEAD_ROWS_CASE(1, 8) PYZ_HEAD_ROWS_CASE(1, 12) PYZ_HEAD_ROWS_CASE(1, 16)
     PYZ_HEAD_ROWS_CASE(1, 24) PYZ_HEAD_ROWS_CASE(1, 32)
     PYZ_HEAD_ROWS_CASE(4, 4) PYZ_HEAD_ROWS_CASE(4, 8) PYZ_HEAD_ROWS_CASE(4, 12) PYZ_HEAD_ROWS_CASE(4, 16)

@@ -268,35 +268,51 @@ __device__ __forceinline__ float pyz_row16_allmax(float v) {
   return v;
 }
 
+// The lane-resident part of the last layer's [W; b]: lane l keeps the rows of units l, l + 64, ... and (lane c) b[c].
+// A wave loads it once and uses it for every batch row it takes.
+template <int UT, int NP>
+struct PyzHeadW {
+  float wv[UT][NP];
+  float bias_mine;
+};
+
+template <int UT, int NP>
+__device__ __forceinline__ void pyz_head_load_w(const HeadArgs &g, const int p, const int l, PyzHeadW<UT, NP> &W) {
+  const int K = g.K, N = g.N;
+  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
+  // Operands through buffer descriptors (per-lane byte offsets, range checked against the byte count).
+  // Only the per-lane offset is range checked by the hardware (not the scalar one): units past K get an
+  // out-of-range voffset; a padded class c >= N reads a neighbouring in-range element (or 0 past the
+  // end), which is harmless: z[c] is never used and delta_L[c] = 0 multiplies it
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (K + 1) * N * 4, 0x00020000);
+  constexpr unsigned OOB = 0x7FFFFF00u;
+#pragma unroll
+  for (int t = 0; t < UT; ++t) {
+    const int u = l + 64 * t;
+    const unsigned wo = u < K ? 4u * (unsigned)u * (unsigned)N : OOB;
+#pragma unroll
+    for (int c = 0; c < NP; ++c) W.wv[t][c] = pyz_buf_load(rw, wo + 4u * (unsigned)c, 0u);
+  }
+  W.bias_mine = pyz_buf_load(rw, l < N ? 4u * ((unsigned)K * (unsigned)N + (unsigned)l) : OOB, 0u);  // lane c: b[c]
+}
+
 // The head of ONE batch row m by ONE wave (lane l).
 template <int UT, int NP>
 __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch, const long long row_off, const int p,
-                                             const int m, const int l) {
+                                             const int m, const int l, const PyzHeadW<UT, NP> &W) {
   const int K = g.K, N = g.N;
   long long yrow = m;
   if (g.row_idx) yrow = g.row_idx[row_off + m];
   const float *hp = g.hin + p * g.hin_pstride + (g.gather_hin ? yrow : (long long)m) * g.lda;
-  const float *wl = g.theta + p * g.theta_pstride + g.w_off;
-  // Operands through buffer descriptors (per-lane byte offsets, range checked against the byte count):
   // units past K read as zero.  The class loops below are straight-line code over the NP padded
   // classes: no per-class branches (conditional writes into the register arrays would turn them
   // into whole-vector copies).
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (K + 1) * N * 4, 0x00020000);
-  constexpr unsigned OOB = 0x7FFFFF00u;
-  float hv[UT], wv[UT][NP], z[NP];
+  const auto &wv = W.wv;
+  const float bias_mine = W.bias_mine;
+  float hv[UT], z[NP];
 #pragma unroll
-  for (int t = 0; t < UT; ++t) {
-    const int u = l + 64 * t;
-    hv[t] = pyz_buf_load(rh, 4u * (unsigned)u, 0u);
-    // only the per-lane offset is range checked by the hardware (not the scalar one): units past K get an
-    // out-of-range voffset; a padded class c >= N reads a neighbouring in-range element (or 0 past the
-    // end), which is harmless: z[c] is never used and delta_L[c] = 0 multiplies it below
-    const unsigned wo = u < K ? 4u * (unsigned)u * (unsigned)N : OOB;
-#pragma unroll
-    for (int c = 0; c < NP; ++c) wv[t][c] = pyz_buf_load(rw, wo + 4u * (unsigned)c, 0u);
-  }
-  const float bias_mine = pyz_buf_load(rw, l < N ? 4u * ((unsigned)K * (unsigned)N + (unsigned)l) : OOB, 0u);  // lane c: b[c]
+  for (int t = 0; t < UT; ++t) hv[t] = pyz_buf_load(rh, 4u * (unsigned)(l + 64 * t), 0u);
   int ylab = 0;
   if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
   PYZ_STAMP(1, 1);
@@ -404,18 +420,31 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
   PYZ_STAMP(1, 5);
 }
 
-template <int UT, int NP>
+// RW = batch rows per wave: 1 when the launch has few rows (a single chain: every row its own wave, the chip is
+// barely filled as it is), 4 when there are tens of thousands (64 particles x 1024 rows): the wave's share of
+// [W; b] -- UT x NP strided loads, most of the kernel's memory instructions -- is then fetched once for four rows.
+template <int UT, int NP, int RW = 1>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
   const int w = pyz_wave_id(), l = threadIdx.x & 63;
   const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
   const int batch = ctl.batch, p = blockIdx.y;
-  const int m = blockIdx.x * 4 + w;  // this wave's batch row (scalar)
-  if (m >= batch) {
-    if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
+  const int m0 = (blockIdx.x * 4 + w) * RW;  // this wave's first batch row (scalar)
+  if (m0 >= batch) {
+    if (l < RW && m0 + l < g.nblk) g.part[p * g.nblk + m0 + l] = 0.0;
     return;
   }
-  pyz_head_row<UT, NP>(g, batch, ctl.row_off, p, m, l);
+  PyzHeadW<UT, NP> W;
+  pyz_head_load_w<UT, NP>(g, p, l, W);
+#pragma unroll 1
+  for (int rr = 0; rr < RW; ++rr) {
+    const int m = m0 + rr;
+    if (m >= batch) {   // uniform
+      if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
+      continue;
+    }
+    pyz_head_row<UT, NP>(g, batch, ctl.row_off, p, m, l, W);
+  }
 }
 
 // ---------------------------------------------------------------- all weight gradients + update

@@ -155,6 +155,29 @@ def test_wide_layers_many_particles(eng, monkeypatch, lds):
     plan.close()
 
 
+def test_many_rows_take_four_rows_per_head_wave(eng):
+    """64 particles x 1 003 gathered rows (> 32 768 rows in the launch): the head kernel gives every wave FOUR
+    batch rows and loads its share of the last layer once for them (k_head_rows<.., 4>); the ragged end (1 003 is not
+    a multiple of four) and the loss partials past the batch are what this covers.  Losses and gradients against
+    the oracle."""
+    spec = o_mlp.MLPSpec((48, 72, 10), ("tanh", "softmax"), "scce")
+    rng = np.random.default_rng(78)
+    x = rng.normal(size=(1200, 48)).astype(np.float32)
+    y = rng.integers(0, 10, size=1200).astype(np.int32)
+    P, b = 64, 1003
+    thetas = (rng.normal(size=(P, spec.n_params)) * 0.2).astype(np.float32)
+    idx = rng.permutation(1200)[:b].astype(np.int32)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=1024, max_particles=P)
+    with eng.KernelProbe(16) as kp:
+        loss, grad = plan.loss_grad(dev(thetas), dev(x), dev(y, torch.int32), batch=b, row_idx=dev(idx, torch.int32))
+    assert any(name.startswith("k_head_rows") and name.rstrip(">").endswith(", 4") for name, _ in kp.launches), kp.launches
+    for p in (0, 5, 33, 63):
+        rl, rg, _ = o_mlp.loss_and_grad(thetas[p], x[idx], y[idx], spec)
+        close(loss[p:p + 1], [rl], what=f"loss[{p}]")
+        close(grad[p], rg, what=f"grad[{p}]")
+    plan.close()
+
+
 def test_full_size_mnist_gradient(eng):
     """BASELINE config 2 shapes: 784 -> 200 -> 10, batch 1024 (and the ragged 896)."""
     spec = o_mlp.MLPSpec((784, 200, 10), ("relu", "softmax"), "scce")
