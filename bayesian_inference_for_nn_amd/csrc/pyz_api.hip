@@ -1272,11 +1272,12 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
     const int dist_rows = median ? n_total : n_local, dist_row0 = median ? 0 : row0;
     const size_t n_part = (size_t)dist_rows * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
     const size_t n_dmat = median ? (size_t)n_total * 64 + 8 : 0;
-    if ((rc = need_part2(m, n_part + n_k + n_local + n_diag + n_dmat + 16))) return rc;
+    if ((rc = need_part2(m, n_part + n_k + 2 * (size_t)n_local + n_diag + n_dmat + 16))) return rc;
     ta.part = full(m)->x.part2;
     ta.kmat = ta.part + n_part;
-    ta.ksum = reinterpret_cast<float *>(ta.kmat + n_k);
-    double *after_ksum = ta.kmat + n_k + (n_local + 1) / 2 + 1;
+    ta.ksumd = ta.kmat + n_k;
+    ta.ksum = reinterpret_cast<float *>(ta.ksumd + n_local);
+    double *after_ksum = ta.ksumd + n_local + (n_local + 1) / 2 + 1;
     // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
     // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
     const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
@@ -1301,7 +1302,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
     }
     PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta, 0);
     PYZ_LAUNCH(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum,
-               (const double *)ta.gamma_dev);
+               (const double *)ta.ksumd, (const double *)ta.gamma_dev);
   } else if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
     PYZ_LAUNCH(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);

@@ -690,7 +690,8 @@ struct SvgdTileArgs {
   int nblk;
   int range;               // elements of D per workgroup of k_svgd_dist_tile (multiple of PYZ_SV_E)
   double *kmat;            // (n_local, 64) kernel values (0 past M)
-  float *ksum;             // (n_local)
+  float *ksum;             // (n_local) sum_j K_ij, float (the factor of the loss gradient)
+  double *ksumd;           // (n_local) the same row sum in float64, in the update kernel's summation order
   double *diag;            // Gram form only: (nblk, 64) partial squared norms of all particles; else nullptr
   // median-heuristic bandwidth (SVGD.py:165-181) only: the squared distances of ALL pairs and the bandwidth they give
   double *dmat;            // (M, 64) squared distances (0 past M), or nullptr
@@ -943,8 +944,16 @@ __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dis
   const double k = j < g.M ? exp(-gam * d) : 0.0;
   g.kmat[il * 64 + j] = k;
   float ks = 0.0f;
-  for (int u = 0; u < g.M; ++u) ks += (float)__shfl(k, u, 64);
-  if (j == 0) g.ksum[il] = ks;
+  double k4[4] = {0.0, 0.0, 0.0, 0.0};   // four interleaved partial sums, combined in a fixed order (k_svgd_update_tile's
+  for (int u = 0; u < g.M; ++u) {        //  arithmetic for x_i sum_j K_ij: the sum is row-constant, taken once here)
+    const double ku = __shfl(k, u, 64);
+    ks += (float)ku;
+    k4[u & 3] += ku;
+  }
+  if (j == 0) {
+    g.ksum[il] = ks;
+    g.ksumd[il] = (k4[0] + k4[1]) + (k4[2] + k4[3]);
+  }
 }
 
 // The median heuristic of SVGD.baseline__kernel (SVGD.py:165-181, dead code in the reference; opt-in here):
@@ -987,6 +996,7 @@ __global__ void __launch_bounds__(1024) k_svgd_median(SvgdTileArgs g) {
 // from LDS cost one 512-byte broadcast per (row, j) and made the kernel LDS-bound (222 us).
 __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const double *__restrict__ kmat,
                                                           const float *__restrict__ ksum,
+                                                          const double *__restrict__ ksumd,
                                                           const double *__restrict__ gamma_dev) {
   const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
   if (d >= g.D) return;
@@ -1008,13 +1018,10 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
     // cancellation error, far below float32 phi.  Four interleaved partial sums (j mod 4), combined in a fixed
     // order: a single chain of 64 dependent float64 FMAs would run at their latency, not their rate
     const double xid = (double)xi;
-    double r4[4] = {0.0, 0.0, 0.0, 0.0}, k4[4] = {0.0, 0.0, 0.0, 0.0};
+    double r4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      r4[j & 3] += kr[j] * xj[j];
-      k4[j & 3] += kr[j];          // (wave-uniform: scalar-side work)
-    }
-    double rep = xid * ((k4[0] + k4[1]) + (k4[2] + k4[3])) - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+    for (int j = 0; j < 64; ++j) r4[j & 3] += kr[j] * xj[j];
+    double rep = xid * ksumd[il] - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
     rep *= two_gamma;
     const long long o = (long long)il * g.D + d;
     const float phi = (ksum[il] * g.grad[o] + (float)rep) / (float)g.M;
