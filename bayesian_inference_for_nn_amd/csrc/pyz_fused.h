@@ -296,10 +296,12 @@ __device__ __forceinline__ void pyz_head_load_w(const HeadArgs &g, const int p, 
   W.bias_mine = pyz_buf_load(rw, l < N ? 4u * ((unsigned)K * (unsigned)N + (unsigned)l) : OOB, 0u);  // lane c: b[c]
 }
 
-// The head of ONE batch row m by ONE wave (lane l).
-template <int UT, int NP>
+// The head of ONE batch row m by ONE wave (lane l).  PRELOADED: W already holds the wave's share of [W; b] (several
+// rows per wave); else it is fetched here, behind the row's own loads (one row per wave: the order of round 1 --
+// with the 48 strided [W; b] loads in front of them the row's input and label chain start 0.4 us later).
+template <int UT, int NP, bool PRELOADED>
 __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch, const long long row_off, const int p,
-                                             const int m, const int l, const PyzHeadW<UT, NP> &W) {
+                                             const int m, const int l, PyzHeadW<UT, NP> &W) {
   const int K = g.K, N = g.N;
   long long yrow = m;
   if (g.row_idx) yrow = g.row_idx[row_off + m];
@@ -308,11 +310,12 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
   // classes: no per-class branches (conditional writes into the register arrays would turn them
   // into whole-vector copies).
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
-  const auto &wv = W.wv;
-  const float bias_mine = W.bias_mine;
   float hv[UT], z[NP];
 #pragma unroll
   for (int t = 0; t < UT; ++t) hv[t] = pyz_buf_load(rh, 4u * (unsigned)(l + 64 * t), 0u);
+  if (!PRELOADED) pyz_head_load_w<UT, NP>(g, p, l, W);
+  const auto &wv = W.wv;
+  const float bias_mine = W.bias_mine;
   int ylab = 0;
   if (g.loss == PYZ_LOSS_SCCE) ylab = reinterpret_cast<const int32_t *>(g.y)[yrow];
   PYZ_STAMP(1, 1);
@@ -435,6 +438,10 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
     return;
   }
   PyzHeadW<UT, NP> W;
+  if (RW == 1) {
+    pyz_head_row<UT, NP, false>(g, batch, ctl.row_off, p, m0, l, W);
+    return;
+  }
   pyz_head_load_w<UT, NP>(g, p, l, W);
 #pragma unroll 1
   for (int rr = 0; rr < RW; ++rr) {
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
       if (l == 0 && m < g.nblk) g.part[p * g.nblk + m] = 0.0;
       continue;
     }
-    pyz_head_row<UT, NP>(g, batch, ctl.row_off, p, m, l, W);
+    pyz_head_row<UT, NP, true>(g, batch, ctl.row_off, p, m, l, W);
   }
 }
 
