@@ -41,5 +41,8 @@ t0 = t[:, :, 0].min(axis=1, keepdims=True)
 for s_, lab in enumerate(labels):
     rel = t[:, :, s_] - t0
     print(f"   {lab:40s} median {np.median(rel):8.0f}   p10 {np.percentile(rel, 10):8.0f}   p90 {np.percentile(rel, 90):8.0f} ns")
+sh = a[0, :, :4, :, 0][a[0, :, 0, 0, 1] > 0]          # shader-clock stamps (s_memtime) of the same workgroups
+clk = (sh[:, :, 6] - sh[:, :, 1]) / ((t[:, :, 6] - t[:, :, 1]) * 1e-9) / 1e9
+print(f"   shader clock over the slab loop: median {np.median(clk):.2f} GHz (min {clk.min():.2f}, max {clk.max():.2f})")
 d = t[:, :, 3] - t[:, :, 2]
 print(f"   slab 24, matrix instructions: median {np.median(d):.0f} ns; stage {np.median(t[:, :, 4] - t[:, :, 3]):.0f}; barrier wait {np.median(t[:, :, 5] - t[:, :, 4]):.0f}")
