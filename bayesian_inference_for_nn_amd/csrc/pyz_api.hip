@@ -100,9 +100,9 @@ int check_call(const pyz_mlp *m, int P, int batch) {
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int set_ctl(pyz_mlp *m, int slot, int batch, float lr, long long n, long long row_off, int i, hipStream_t st,
-            int slot0 = 0) {
+            int slot0 = 0, int n_run = 0) {
   m->pend_on = false;
-  PYZ_LAUNCH(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0);
+  PYZ_LAUNCH(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl + slot, batch, lr, n, row_off, i, slot0, n_run);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -120,7 +120,7 @@ void flush_ctl(pyz_mlp *m, hipStream_t st) {
   if (!m->pend_on) return;
   m->pend_on = false;
   PYZ_LAUNCH(k_set_ctl, dim3(1), dim3(1), 0, st, m->ctl, m->pend.batch, m->pend.lr, m->pend.n, m->pend.row_off, m->pend.i,
-                     m->pend.slot0);
+                     m->pend.slot0, 0);
 }
 
 // arguments of the forward pass of layer l (activations land in m->act[l])
@@ -161,8 +161,11 @@ void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, c
                     const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st,
                     float *gather_out = nullptr, int l_end = -1) {
   if (l_end < 0) l_end = m->L;
-  for (int l = 0; l < l_end; ++l)
-    pyz_launch_fwd(forward_args(m, l, theta, theta_ps, x, row_idx, ctl, gather_out), grid_batch, P, st);
+  for (int l = 0; l < l_end; ++l) {
+    DenseArgs g = forward_args(m, l, theta, theta_ps, x, row_idx, ctl, gather_out);
+    g.wt = pyz_wt_for(P);
+    pyz_launch_fwd(g, grid_batch, P, st);
+  }
 }
 
 void launch_loss(pyz_mlp *m, int P, const void *y, const int32_t *row_idx, int grid_batch, const StepCtl *ctl,
@@ -270,6 +273,7 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
   g.prev_pstride = (long long)m->max_batch * g.K;
   g.part = m->part;
   g.ctl = ctl;
+  g.wt = pyz_wt_for(P);
   if (m->pend_on && ctl == m->ctl) {  // no hidden layer: the head is the first kernel of the eager step
     g.init = m->pend;
     g.init_on = 1;
@@ -361,8 +365,10 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   a.nblk = m->cur_nblk;
   a.tiles = tiles;
   a.nonfinite = m->nonfinite;
+  a.wt = pyz_wt_for(P);
   const int S = pyz_pick_waves((long long)tiles * P, (grid_batch + 1) / 2);
-  const dim3 grid(pyz_pad8((long long)tiles + 1, P), P);  // + the duties workgroup (+ padding, see pyz_pad8)
+  dim3 grid(pyz_pad8((long long)tiles + 1, P), P);  // + the duties workgroup (+ padding, see pyz_pad8)
+  if (a.prep.src && P == 1) grid.x = (unsigned)(tiles + 1 + std::max(pyz_cu_count() - tiles - 1, 24));  // + the batch workers
   switch (S) {
     case 1:
       if (a.mode == PYZ_UPD_NONE) PYZ_LAUNCH((k_wgrad_all<1, true>), grid, dim3(64), 0, st, a);
@@ -375,11 +381,42 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
   }
 }
 
-// forward + loss (+ backward into `grad` when upd.mode == NONE and grad given, or the fused update)
+inline float *batch_buf(pyz_mlp *m, int slot) { return m->xb + (size_t)slot * m->max_batch * m->dims[0]; }
+
+// chained runs whose batches are assembled one step ahead (PrepArgs, pyz_fused.h): single chain, fused path, a hidden layer
+inline bool batch_ahead(const pyz_mlp *m, const int32_t *row_idx) {
+  static const int on = pyz_env_int("PYZ_BATCH_AHEAD", 1);
+  return on && can_fuse(m) && m->L > 1 && row_idx != nullptr;
+}
+
+PrepArgs prep_args(pyz_mlp *m, const float *x, const int32_t *row_idx, int grid_batch, long long row_stride, int dst_slot) {
+  PrepArgs p{};
+  p.src = x;
+  p.dst = batch_buf(m, dst_slot);
+  p.row_idx = row_idx;
+  p.tab_bs = m->tab_bs;
+  p.row_stride = row_stride;
+  p.K = p.lda = m->dims[0];
+  p.fwd_tiles_n = (m->dims[1] + 31) / 32;
+  p.fwd_tiles = ((grid_batch + 31) / 32) * p.fwd_tiles_n;
+  return p;
+}
+
+// forward + loss (+ backward into `grad` when upd.mode == NONE and grad given, or the fused update).
+// ahead_slot >= 0 (chained runs): this step's rows already stand in batch_buf(ahead_slot), and upd.prep says where the
+// weight-gradient launch assembles the next step's.
 void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
-                          hipStream_t st) {
+                          hipStream_t st, int ahead_slot = -1) {
   if (can_fuse(m)) {
+    if (ahead_slot >= 0) {
+      const float *xc = batch_buf(m, ahead_slot);
+      launch_forward(m, theta, theta_ps, P, xc, nullptr, grid_batch, ctl, st, nullptr, m->L - 1);
+      launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);   // (labels go through row_idx)
+      launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
+      launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xc);
+      return;
+    }
     static const int use_xb = pyz_env_int("PYZ_GATHER_COPY", 1);  // 1: forward leaves a contiguous batch copy
     float *xb = (use_xb && want_grad && row_idx && m->L > 1) ? m->xb : nullptr;
     launch_forward(m, theta, theta_ps, P, x, row_idx, grid_batch, ctl, st, xb, m->L - 1);   // hidden layers
@@ -473,7 +510,8 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     m->ws_bytes += 2 * bytes;
   }
   {
-    const size_t bytes = sizeof(float) * (size_t)max_batch * m->dims[0] + 64;
+    // two contiguous batches: chained runs assemble step s + 1's rows in the one that step s does not read
+    const size_t bytes = 2 * sizeof(float) * (size_t)max_batch * m->dims[0] + 64;
     if (hipMalloc((void **)&m->xb, bytes) != hipSuccess) return fail(pyz_fail(PYZ_E_OOM, "workspace allocation of %zu bytes failed", bytes));
     m->ws_bytes += bytes;
   }
@@ -651,7 +689,9 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
     u.tab_bs = m->tab_bs;
     u.tab_lr = m->tab_lr;
     u.row_stride = row_stride;
-    launch_loss_backward(m, theta, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st);
+    const bool ahead = chained && batch_ahead(m, row_idx);
+    if (ahead) u.prep = prep_args(m, x, row_idx, grid_batch, row_stride, slot ^ 1);
+    launch_loss_backward(m, theta, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st, ahead ? slot : -1);
     return;
   }
   WgradArgs u{};
@@ -773,8 +813,11 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     PYZ_HIP(hipMemcpyAsync(m->tab_bs, hb, sizeof(int32_t) * n_tab, hipMemcpyHostToDevice, st));
     PYZ_HIP(hipMemcpyAsync(m->tab_lr, hl, sizeof(float) * n_tab, hipMemcpyHostToDevice, st));
     PYZ_HIP(hipEventRecord(f->x.tab_ev[slot], st));
-    if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0))) return rc;
+    if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0, n_steps))) return rc;
   }
+
+  if (batch_ahead(m, d_row_idx))   // the first batch of the run (every later one is assembled by the step before it)
+    PYZ_LAUNCH(k_prep_batch, dim3(256), dim3(256), 0, st, prep_args(m, d_x, d_row_idx, bmax, row_stride, 0), m->ctl);
 
   int s = 0;
   m->run_graph_steps = m->run_eager_steps = m->run_graph_launches = 0;

@@ -41,6 +41,7 @@ struct HeadArgs {
   const StepCtl *ctl;
   StepCtl init;              // the step scalars by value when the head is the first kernel of an eager step (L == 1)
   int init_on;
+  int wt;                    // write-through stores for the outputs (pyz_st)
 };
 
 // lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
@@ -404,8 +405,8 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
   }
   PYZ_STAMP(1, 3);
   if (l < N) {
-    if (g.out_last) g.out_last[p * g.last_pstride + (long long)m * N + l] = my_o;
-    if (g.delta_last) g.delta_last[p * g.last_pstride + (long long)m * N + l] = my_d;
+    if (g.out_last) pyz_st(g.out_last + p * g.last_pstride + (long long)m * N + l, my_o, g.wt);
+    if (g.delta_last) pyz_st(g.delta_last + p * g.last_pstride + (long long)m * N + l, my_d, g.wt);
   }
   if (l == 0) g.part[p * g.nblk + m] = (double)lm;
   PYZ_STAMP(1, 4);
@@ -418,7 +419,7 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
     float a = 0.0f;
 #pragma unroll
     for (int c = 0; c < NP; ++c) a = fmaf(d2[c], wv[t][c], a);
-    if (u < K) op[u] = a * pyz_act_grad(hv[t], actp);
+    if (u < K) pyz_st(op + u, a * pyz_act_grad(hv[t], actp), g.wt);
   }
   PYZ_STAMP(1, 5);
 }
@@ -452,6 +453,90 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
     }
     pyz_head_row<UT, NP, true>(g, batch, ctl.row_off, p, m, l, W);
   }
+}
+
+// ---------------------------------------------------------------- the next step's batch, assembled ahead of its step
+// In a device-resident run the rows of step s + 1 are known while step s runs (row table + per-run tables).  The
+// workgroups of k_wgrad_all that own no tile -- 73 of the 256 CUs idle at C2 -- copy those rows of the resident data
+// set into the other one of two contiguous (max_batch, K) buffers.  The forward pass of step s + 1 then reads plain
+// contiguous rows: no index load in front of its first operand load, no first touch of HBM rows on its critical
+// path, no copy to store for the weight-gradient kernel.  A worker takes rows that the forward tiles of workgroups
+// with its own blockIdx % 8 read (workgroups are dealt round-robin over the XCDs: the copy then waits in the L2 of
+// the XCD that reads it; placement only changes speed).
+struct PrepArgs {
+  const float *src;           // (n_rows, lda) resident data set; nullptr: no preparation in this launch
+  float *dst;                 // (max_batch, K) contiguous batch of the NEXT step
+  const int32_t *row_idx;     // the run's row table
+  const int32_t *tab_bs;      // per-run batch sizes
+  long long row_stride;
+  int K, lda;
+  int fwd_tiles, fwd_tiles_n; // tile grid of the forward kernel that will read dst (pyz_xcd_remap over fwd_tiles ids)
+};
+
+// rows [ra, rb) of the batch whose row indices start at idx: dst[m][:] = src[idx[m]][:]
+__device__ __forceinline__ void pyz_copy_rows(const PrepArgs &g, const int32_t *idx, const int ra, const int rb) {
+  const int K = g.K, nt = blockDim.x, t = threadIdx.x;
+  if (ra >= rb) return;
+  if ((K & 3) == 0 && (g.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.src) | reinterpret_cast<uintptr_t>(g.dst)) & 15) == 0) {
+    const int K4 = K >> 2, total = (rb - ra) * K4;
+    for (int e0 = t; e0 < total; e0 += 4 * nt) {   // four independent 16-byte loads per thread and trip
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + u * nt, total - 1), m = ra + e / K4, c = e % K4;
+        v[u] = *reinterpret_cast<const float4 *>(g.src + (long long)idx[m] * g.lda + 4 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nt;
+        if (e < total) {
+          float *d = g.dst + (long long)(ra + e / K4) * K + 4 * (e % K4);
+          // write-through (sc1) stores: the copy leaves L2 while the tile workgroups still run.  With plain stores the
+          // 3.2 MB stay dirty in L2 until the kernel ends and its end waits for their write-back (measured at C2:
+          // k_wgrad_all 10.75 against 10.3 us; the stand-alone first-batch launch 28 against 4 us)
+          const f32x4 vv = {v[u].x, v[u].y, v[u].z, v[u].w};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d), "v"(vv) : "memory");
+        }
+      }
+    }
+    return;
+  }
+  const int total = (rb - ra) * K;
+  for (int e = t; e < total; e += nt) {
+    const int m = ra + e / K, c = e % K;
+    g.dst[(long long)m * K + c] = g.src[(long long)idx[m] * g.lda + c];
+  }
+}
+
+// worker j of cnt (its workgroup id is bid): its share of the nb rows
+__device__ __forceinline__ void pyz_prep_rows(const PrepArgs &g, const int32_t *idx, const int nb, const int j, const int cnt,
+                                              const int bid) {
+  int ra, rb;
+  if (cnt >= 8 && g.fwd_tiles >= 8) {
+    // the forward tiles of the workgroups with id % 8 == x: ids [t0, t1) after pyz_xcd_remap, i.e. row blocks from t0 / tiles_n
+    const int x = bid & 7, q = g.fwd_tiles >> 3, r = g.fwd_tiles & 7;
+    const int t0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, t1 = t0 + (x < r ? q + 1 : q);
+    // rows whose first tile lies in [t0, t1)
+    const int b0 = (t0 + g.fwd_tiles_n - 1) / g.fwd_tiles_n, b1 = (t1 + g.fwd_tiles_n - 1) / g.fwd_tiles_n;
+    const int r0 = min(32 * b0, nb), r1 = x == 7 ? nb : min(32 * b1, nb);
+    // the workers with this residue: ids first, first + 8, ... (first = the smallest id >= bid - 8 j with id % 8 == x)
+    const int id0 = bid - j;                       // id of worker 0
+    const int first = id0 + ((x - (id0 & 7)) & 7); // first worker id with residue x
+    const int mine = (bid - first) >> 3, all = (id0 + cnt - 1 - first) / 8 + 1;
+    const int per = (r1 - r0 + all - 1) / all;
+    ra = r0 + mine * per;
+    rb = min(ra + per, r1);
+  } else {
+    const int per = (nb + cnt - 1) / cnt;
+    ra = j * per;
+    rb = min(ra + per, nb);
+  }
+  pyz_copy_rows(g, idx, ra, rb);
+}
+
+// the first batch of a run (nobody ran before it): the same copy as a launch of its own
+__global__ void k_prep_batch(PrepArgs g, const StepCtl *ctl) {
+  pyz_prep_rows(g, g.row_idx + ctl->row_off, ctl->batch, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------- all weight gradients + update
@@ -509,6 +594,8 @@ struct WgradArgs {
   const float *tab_lr;
   long long row_stride;
   int *nonfinite;             // device counter of steps with a NaN / Inf loss (may be nullptr)
+  int wt;                     // write-through stores for the updated state (pyz_st)
+  PrepArgs prep;              // chained runs: the workgroups past the duties workgroup assemble the NEXT step's batch
 };
 
 // ---------------------------------------------------------------- the optimizer updates (shared by the
@@ -576,9 +663,9 @@ __device__ __forceinline__ void pyz_update_store(const WgradArgs &g, const int m
     g.grad[p * g.grad_pstride + e] = gv;
     return;
   }
-  g.theta[e] = o.th;
-  if (o.wr_mu) g.mean[e] = o.mu;
-  if (o.wr_sq) g.sq_mean[e] = o.sq;
+  pyz_st(g.theta + e, o.th, g.wt);
+  if (o.wr_mu) pyz_st(g.mean + e, o.mu, g.wt);
+  if (o.wr_sq) pyz_st(g.sq_mean + e, o.sq, g.wt);
   if (o.wr_dev) o.dev_row[e] = o.dev;
 }
 
@@ -655,8 +742,15 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   const int r = l & 31, h = l >> 5;
   // workgroup `tiles` (the last id) owns no tile: its first wave does the duties of the step that do
   // not depend on the gradient, off the critical path of the tile workgroups
-  if (blockIdx.x >= (unsigned)g.tiles) {  // (ids past `tiles` + 1 only pad the launch to a multiple of 8)
+  if (blockIdx.x >= (unsigned)g.tiles) {  // (without a batch to prepare, ids past `tiles` + 1 only pad the launch)
     if (blockIdx.x == (unsigned)g.tiles && blockIdx.y == 0 && w == 0) pyz_step_duties(g, l);
+    if (!PLAIN && blockIdx.x > (unsigned)g.tiles && blockIdx.y == 0 && g.prep.src) {
+      const int i2 = g.ctl->i + 1;
+      if (i2 < g.ctl->n_run)
+        pyz_prep_rows(g.prep, g.prep.row_idx + g.ctl->row_off + g.prep.row_stride, g.prep.tab_bs[i2],
+                      (int)blockIdx.x - g.tiles - 1, (int)gridDim.x - g.tiles - 1, (int)blockIdx.x);
+      PYZ_STAMP(2, 3);
+    }
     return;
   }
   const int tile = pyz_xcd_remap(blockIdx.x, g.tiles);

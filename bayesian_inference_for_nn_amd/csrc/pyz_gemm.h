@@ -47,6 +47,7 @@ struct DenseArgs {
   float *gather_out;          // optional (max_batch, K): contiguous copy of the gathered rows (forward, layer 0)
   StepCtl init;               // forward only: the step scalars by value when this is the first kernel of an eager step
   int init_on;
+  int wt;                     // forward: write-through stores for the activations (pyz_st)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids
@@ -319,10 +320,10 @@ __global__ void k_dense_fwd(DenseArgs g) {
   pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h, gp, tiles_n, tile % tiles_n);
   PYZ_STAMP(0, 2);
   float *op = g.out + p * g.out_pstride;
-  const int act = g.act;
+  const int act = g.act, wt = g.wt;
   pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
     const int mm = m0 + ro, nn = n0 + co;
-    if (mm < batch && nn < N) op[(long long)mm * N + nn] = pyz_act(v, act);
+    if (mm < batch && nn < N) pyz_st(op + (long long)mm * N + nn, pyz_act(v, act), wt);
   });
   PYZ_STAMP(0, 3);
 }
@@ -571,6 +572,23 @@ __global__ void k_dense_bwd_weight(DenseArgs g) {
 static inline int pyz_env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v && *v ? atoi(v) : dflt;
+}
+
+// compute units of the current device (256 on MI355X); 256 if the query fails
+static inline int pyz_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// single-chain launches store their outputs write-through (pyz_st); PYZ_WT=0: plain stores
+static inline int pyz_wt_for(int P) {
+  static const int on = pyz_env_int("PYZ_WT", 1);
+  return (on && P == 1) ? 1 : 0;
 }
 
 // waves per workgroup: split the reduction until the launch covers the chip

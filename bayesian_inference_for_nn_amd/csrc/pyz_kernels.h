@@ -61,7 +61,8 @@ __device__ __forceinline__ void pyz_note_loss(int *counter, const float v) {
 }
 
 // ---------------------------------------------------------------- step control
-__global__ void k_set_ctl(StepCtl *ctl, int batch, float lr, long long n, long long row_off, int i, int slot0) {
+__global__ void k_set_ctl(StepCtl *ctl, int batch, float lr, long long n, long long row_off, int i, int slot0, int n_run) {
+  ctl->n_run = n_run;
   ctl->batch = batch;
   ctl->lr = lr;
   ctl->n = n;
@@ -92,6 +93,7 @@ __global__ void k_set_ctl_tabs(StepCtl *ctl, InlineTabs t, int32_t *tab_bs, floa
     ctl->row_off = row_off;
     ctl->i = 0;
     ctl->slot0 = slot0;
+    ctl->n_run = t.n - 1;
   }
 }
 
@@ -106,6 +108,7 @@ __device__ __forceinline__ void pyz_prepare_next(const StepCtl *ctl, StepCtl *ne
   next->n = ctl->n + 1;
   next->row_off = ctl->row_off + row_stride;
   next->slot0 = ctl->slot0;
+  next->n_run = ctl->n_run;
 }
 
 // ---------------------------------------------------------------- losses

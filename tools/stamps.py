@@ -70,3 +70,12 @@ for k, (nm, slots, nb, nw) in names.items():
         per_wave = np.median(rel, axis=0)
         print(f"   {label:22s} median over waves {np.median(rel):7.0f}  min-wave {per_wave.min():7.0f}  max-wave {per_wave.max():7.0f}   per wave: "
               + " ".join(f"{v:5.0f}" for v in per_wave))
+
+# batch workers of k_wgrad_all (the workgroups past the duties workgroup): start .. end relative to the kernel's first workgroup
+tw = a[2, :, :, :, 1] * 10.0
+k0 = tw[:182, :, 0][tw[:182, :, 0] > 0].min()
+pw = tw[183:256]
+ok = pw[:, 0, 3] > 0
+if ok.any():
+    st_, en_ = pw[ok][:, 0, 0] - k0, pw[ok][:, :, 3].max(axis=1) - k0
+    print(f"== k_wgrad_all batch workers: {ok.sum()} workgroups; start median {np.median(st_):.0f} (max {st_.max():.0f}); end median {np.median(en_):.0f}  max {en_.max():.0f} ns after the kernel's first workgroup started")
