@@ -164,6 +164,7 @@ void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, c
   for (int l = 0; l < l_end; ++l) {
     DenseArgs g = forward_args(m, l, theta, theta_ps, x, row_idx, ctl, gather_out);
     g.wt = pyz_wt_for(P);
+    if (!g.row_idx && !g.init_on && !g.gather_out) g.rows_cap = std::min(grid_batch, m->max_batch);   // (layer 0 of a caller-owned x: its rows cover grid_batch by contract)
     pyz_launch_fwd(g, grid_batch, P, st);
   }
 }

@@ -48,6 +48,7 @@ struct DenseArgs {
   StepCtl init;               // forward only: the step scalars by value when this is the first kernel of an eager step
   int init_on;
   int wt;                     // forward: write-through stores for the activations (pyz_st)
+  int rows_cap;               // forward, k_dense_fwd: > 0 = readable rows of a contiguous `in` (see the kernel)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids
@@ -188,13 +189,19 @@ struct PyzNoUse4 {
   __device__ __forceinline__ void operator()(int, const float4 &) const {}
 };
 
-template <int G, class L, class U>
-__device__ __forceinline__ void pyz_pipe4(int c, const int ce, f32x16 &acc, L load, U use) {
-  if (c >= ce) return;
+template <int G, class L, class U, class H = PyzNoHook>
+__device__ __forceinline__ void pyz_pipe4(int c, const int ce, f32x16 &acc, L load, U use, H hook = H()) {
+  if (c >= ce) {
+    hook();
+    return;
+  }
   float4 an[G], bn[G], a[G], b[G];
   const int last = ce - 1;
 #pragma unroll
   for (int u = 0; u < G; ++u) load(min(c + u, last), an[u], bn[u]);
+  __builtin_amdgcn_sched_barrier(0);
+  hook();   // runs once, behind the first group's loads (see pyz_pipe1)
+  __builtin_amdgcn_sched_barrier(0);
   for (;;) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -219,9 +226,9 @@ __device__ __forceinline__ void pyz_pipe4(int c, const int ce, f32x16 &acc, L lo
   }
 }
 
-template <class L, class U>
-__device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load, U use) {
-  pyz_pipe4<2>(c, ce, acc, load, use);
+template <class L, class U, class H = PyzNoHook>
+__device__ __forceinline__ void pyz_steps4_all(int c, const int ce, f32x16 &acc, L load, U use, H hook = H()) {
+  pyz_pipe4<2>(c, ce, acc, load, use, hook);
 }
 template <class L, class F, class H = PyzNoHook>
 __device__ __forceinline__ void pyz_steps1_all(int s, const int se, f32x16 &acc, L load, F fix, H hook = H()) {
@@ -240,9 +247,11 @@ __device__ __forceinline__ float pyz_buf_load(const __amdgpu_buffer_rsrc_t rsrc,
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
 }
 
+template <class H = PyzNoHook>
 __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap, const float *wl, const int n, const int K,
                                                    const int N, const int vec, const int w, const int S, const int h,
-                                                   float *gp = nullptr, const int copy_mod = 1, const int copy_rem = 0) {
+                                                   float *gp = nullptr, const int copy_mod = 1, const int copy_rem = 0,
+                                                   H hook = H()) {
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wl), 0, (int)((unsigned)(K + 1) * (unsigned)N * 4u), 0x00020000);
   const unsigned n4 = 4u * (unsigned)n, N4 = 4u * (unsigned)N;
@@ -272,7 +281,8 @@ __device__ __forceinline__ void pyz_fwd_accumulate(f32x16 &acc, const float *ap,
           *reinterpret_cast<float4 *>(gp + 8 * c + 4 * h) = a4;
 #endif
         }
-      });
+      },
+      hook);
   const int t0 = 8 * c8, steps = (K - t0 + 1) >> 1;
   const unsigned vt = (unsigned)h * N4 + n4;
   pyz_steps1_all(
@@ -301,23 +311,40 @@ __global__ void k_dense_fwd(DenseArgs g) {
   PYZ_STAMP(0, 0);
   const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
-  const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
-  const int batch = ctl.batch;
   const int tiles_n = (g.N + 31) >> 5;
   const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
-  if (m0 >= batch) return;  // uniform per workgroup
+  // rows_cap > 0 (contiguous input with that many readable rows, e.g. the batch assembled ahead): the operand loads
+  // do not wait for the step scalars -- those come from memory another XCD wrote (a round trip to the Infinity
+  // Cache) and are only needed when the tile is stored: one scalar load, requested in front of the reduction and
+  // waited for behind it.  Rows in [batch, rows_cap) are computed and dropped.
+  int cap = g.rows_cap;
+  long long row_off = 0;
+  if (cap <= 0) {
+    asm volatile("; the step scalars are needed here" ::: "memory");   // (keeps this a branch: a select would wait on both paths)
+    const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
+    cap = __builtin_amdgcn_readfirstlane(ctl.batch);
+    row_off = ctl.row_off;
+  }
+  if (m0 >= cap) return;  // uniform per workgroup
   const int p = blockIdx.y;
   const int K = g.K, N = g.N;
-  const int m = min(m0 + r, batch - 1), n = min(n0 + r, N - 1);  // clamped: rows/cols past the edge are never stored
+  const int m = min(m0 + r, cap - 1), n = min(n0 + r, N - 1);  // clamped: rows/cols past the edge are never stored
   long long row = m;
-  if (g.row_idx) row = g.row_idx[ctl.row_off + m];
+  if (g.row_idx) row = g.row_idx[row_off + m];
   const float *ap = g.in + p * g.in_pstride + row * g.lda;
   const float *wl = g.theta + p * g.theta_pstride + g.w_off;
   f32x16 acc = {0};
   PYZ_STAMP(0, 1);
   float *gp = (g.gather_out && p == 0) ? g.gather_out + (long long)m * K : nullptr;
-  pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h, gp, tiles_n, tile % tiles_n);
+  // The late load is an ordinary vector load (L2-served: the line was written by another kernel) requested behind the
+  // first group of operand loads; vector loads return in order, so it holds back at most the second group.
+  // (Unconditional: behind a branch the compiler loses count of the loads in flight and waits for all of them.)
+  int batch = 0;
+  const int32_t *ctl_batch = &g.ctl->batch;
+  pyz_fwd_accumulate(acc, ap, wl, n, K, N, g.vec, w, S, h, gp, tiles_n, tile % tiles_n,
+                     [&]() { batch = __hip_atomic_load(ctl_batch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+  batch = g.rows_cap > 0 ? __builtin_amdgcn_readfirstlane(batch) : cap;
   PYZ_STAMP(0, 2);
   float *op = g.out + p * g.out_pstride;
   const int act = g.act, wt = g.wt;
