@@ -512,12 +512,12 @@ __global__ void k_dense_bwd_data(DenseArgs g) {
   }
   float *op = g.out + p * g.out_pstride;
   const float *hp = g.aux + p * g.aux_pstride;
-  const int act = g.act;
+  const int act = g.act, wt = g.wt;
   pyz_tile_epilogue(acc, red, [&](int ro, int co, float v) {
     const int mm = m0 + ro, jj = j0 + co;
     if (mm < batch && jj < K) {
       const long long o = (long long)mm * K + jj;
-      op[o] = v * pyz_act_grad(hp[o], act);
+      pyz_st(op + o, v * pyz_act_grad(hp[o], act), wt);
     }
   });
 }

@@ -329,22 +329,34 @@ __global__ void k_bbb_sample(BbbArgs g) {
   const long long e0 = 4 * t;
   double kl = 0.0;
   if (e0 < g.D) {
-    float z[4];
+    float z[4], wv[4];
     pyz_bbb_eps(g, t, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = e0 + j;
+      wv[j] = 0.0f;
       if (e < g.D) {
         const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
         const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), lsp = logf(sp);
         const float mu = g.mu[e], sg = pyz_softplus(g.rho[e]);
         const float w = z[j] * sg + mu;
-        g.w[e] = w;
+        wv[j] = w;
         const float a = (w - mu) / sg, b = (w - pmean) / sp;
         const float lq = -0.5f * a * a - logf(sg) - PYZ_LOG_SQRT_2PI;
         const float lp = -0.5f * b * b - lsp - PYZ_LOG_SQRT_2PI;
         kl += (double)lq - (double)lp;
       }
+    }
+    // the sampled weights are the next kernel's operand: one 16-byte write-through store per thread (whole lines leave L2
+    // while the kernel runs; plain stores would wait for their write-back at its end -- see pyz_st)
+    if (e0 + 3 < g.D && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0) {
+      const f32x4 vv = {wv[0], wv[1], wv[2], wv[3]};
+      float *d = g.w + e0;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d), "v"(vv) : "memory");
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (e0 + j < g.D) g.w[e0 + j] = wv[j];
     }
   }
   const double s = pyz_block_sum(kl, sm);
