@@ -241,7 +241,10 @@ class Optimizer(ABC):
         self._res_idx[:n_steps].copy_(table)
         return self._res_idx, self._res_losses
 
-    _resident_chunks = (128, 512)                    # steps in the first / in every later chunk of a resident run
+    # steps in the first chunk of a resident run, growth from chunk to chunk, largest chunk: laying out a step's batch
+    # costs the host about 15 us (one permutation per epoch), the device takes 24 us for it at C2 -- a chunk may be at most
+    # 1.6 times the one the device is working through, or the device waits for its plan
+    _resident_chunks = (128, 1.5, 512)
 
     def _run_resident_chunks(self, nb_iterations: int, launch):
         """A device-resident run, planned and launched in chunks: the host lays out the batches of the next chunk
@@ -249,12 +252,13 @@ class Optimizer(ABC):
         launch(row_idx, losses, batch_sizes, s0) enqueues steps [s0, s0 + len(batch_sizes)) on the current stream;
         returns the losses of the run (a view of the persistent buffer)."""
         import torch
-        first, chunk = self._resident_chunks
+        first, growth, largest = self._resident_chunks
         self._reserve_resident(nb_iterations)
         main, stream = torch.cuda.current_stream(), torch.cuda.Stream()      # (graph replay needs its own stream)
-        s0 = 0
+        s0, size = 0, float(first)
         while s0 < nb_iterations:
-            n = min(first if s0 == 0 else chunk, nb_iterations - s0)
+            n = min(max(1, int(size)), nb_iterations - s0)
+            size = min(size * growth, float(largest))
             table, sizes = self._batch_plan(n)
             self._res_idx[s0:s0 + n].copy_(table)
             stream.wait_stream(main)

@@ -92,7 +92,7 @@ def test_sgld_surface_matches_oracle_and_resident_training():
     a, b2 = SGLD(), SGLD()
     a.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
     b2.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
-    a._resident_chunks = (40, 20)                            # planned and launched as 40 + 20 + 10 steps
+    a._resident_chunks = (40, 0.5, 40)                          # planned and launched as 40 + 20 + 10 steps
     a.train(70)
     b2._nb_iterations = 70
     b2._init_sgld_lr()
@@ -329,7 +329,7 @@ def test_swag_quiet_train_is_the_step_loop():
                     starting_model=start, seed=12)
         return opt
     a, b = make(), make()
-    a._resident_chunks = (16, 12)                            # several plan/launch chunks per run
+    a._resident_chunks = (16, 0.75, 16)                          # several plan/launch chunks per run
     a.train(40)
     a.train(37)                                              # a second run continues the count (77 steps: 16 hits)
     for _ in range(77):
