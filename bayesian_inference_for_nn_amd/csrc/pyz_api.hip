@@ -789,6 +789,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     f->x.tab_count = 0;
   }
   const long long row_stride = m->max_batch;
+  bool first_batch_done = false;
   if (n_steps <= PYZ_INLINE_TAB) {
     // short run: the tables ride in the arguments of the launch that sets the first step's scalars
     InlineTabs tabs{};
@@ -800,7 +801,13 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     tabs.lr[n_steps] = h_lr[n_steps - 1];
     tabs.n = n_steps + 1;
     m->pend_on = false;
-    PYZ_LAUNCH(k_set_ctl_tabs, dim3(1), dim3(64), 0, st, m->ctl, tabs, m->tab_bs, m->tab_lr, (long long)n0, slot0 * row_stride, (int)slot0);
+    if (batch_ahead(m, d_row_idx)) {   // ... together with the first batch of the run
+      PYZ_LAUNCH(k_run_start, dim3(256), dim3(256), 0, st, m->ctl, tabs, m->tab_bs, m->tab_lr, (long long)n0, slot0 * row_stride,
+                 (int)slot0, prep_args(m, d_x, d_row_idx, bmax, row_stride, 0));
+      first_batch_done = true;
+    } else {
+      PYZ_LAUNCH(k_set_ctl_tabs, dim3(1), dim3(64), 0, st, m->ctl, tabs, m->tab_bs, m->tab_lr, (long long)n0, slot0 * row_stride, (int)slot0);
+    }
   } else {
     const unsigned slot = (unsigned)(f->x.tab_count & 1);
     if (f->x.tab_count >= 2) PYZ_HIP(hipEventSynchronize(f->x.tab_ev[slot]));
@@ -817,7 +824,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     if ((rc = set_ctl(m, 0, h_batch_sizes[0], h_lr[0], n0, slot0 * row_stride, 0, st, (int)slot0, n_steps))) return rc;
   }
 
-  if (batch_ahead(m, d_row_idx))   // the first batch of the run (every later one is assembled by the step before it)
+  if (batch_ahead(m, d_row_idx) && !first_batch_done)   // the first batch of the run (every later one is assembled by the step before it)
     PYZ_LAUNCH(k_prep_batch, dim3(256), dim3(256), 0, st, prep_args(m, d_x, d_row_idx, bmax, row_stride, 0), m->ctl);
 
   int s = 0;

@@ -539,6 +539,30 @@ __global__ void k_prep_batch(PrepArgs g, const StepCtl *ctl) {
   pyz_prep_rows(g, g.row_idx + ctl->row_off, ctl->batch, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
 }
 
+// short runs (the tables travel as kernel arguments): k_set_ctl_tabs and k_prep_batch as ONE launch in front of the
+// first step -- block 0 writes the tables and the first step's scalars, every block copies its share of the first batch
+// (row offset and batch size of that step come as arguments: nothing here reads what block 0 writes)
+__global__ void k_run_start(StepCtl *ctl, InlineTabs t, int32_t *tab_bs, float *tab_lr, long long n, long long row_off,
+                            int slot0, PrepArgs g) {
+  if (blockIdx.x == 0) {
+    const int e = threadIdx.x;
+    if (e < t.n) {
+      tab_bs[e] = t.bs[e];
+      tab_lr[e] = t.lr[e];
+    }
+    if (e == 0) {
+      ctl->batch = t.bs[0];
+      ctl->lr = t.lr[0];
+      ctl->n = n;
+      ctl->row_off = row_off;
+      ctl->i = 0;
+      ctl->slot0 = slot0;
+      ctl->n_run = t.n - 1;
+    }
+  }
+  pyz_prep_rows(g, g.row_idx + row_off, t.bs[0], (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------- all weight gradients + update
 struct WgradLayer {
   const float *in;            // layer input: data x (layer 0) or act[l-1]
