@@ -644,7 +644,15 @@ static inline bool pyz_fwd_takes_lds(const DenseArgs &g, int grid_batch, int P, 
   // (measured: with few row tiles per particle -- C5: 8 -- the LDS kernel wins, 0.23 against 0.32 ms; with many --
   // predict, 79 -- the one-wave kernel runs out of an L2 that keeps its slice of the rows and wins, 14.5 against 16.7 ms)
   const int lds_max_rows = pyz_env_int("PYZ_FWD_LDS_MAXROWS", 2048);
-  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows;
+  // ... and its own 128-row tiles must fill the chip: 16 particles x 8 row tiles = 128 workgroups took 130 us, 2.8 times
+  // the 8-particle launch of the one-wave kernel.  (A third kernel for the sizes in between -- 32-row tiles, the slab's
+  // reduction steps split over the four waves -- was built and measured: with one workgroup per CU and 28 matrix
+  // instructions per wave and slab it cannot hide the latency of its own slab loads: 54 - 60 us at 8 particles against
+  // 46 for the one-wave kernel, 21 - 27 against 13.5 us on the 784 -> 400 layer; removed.)
+  const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
+  const long long wg128 = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT)) * P;
+  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows &&
+         wg128 >= pyz_env_int("PYZ_FWD_LDS_MINWG", 256);
 }
 
 static inline void pyz_launch_fwd(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {

@@ -139,6 +139,7 @@ def test_wide_layers_many_particles(eng, monkeypatch, lds):
     (k_dense_fwd_lds, 128 x 224 per workgroup) -- or, with the switch off, as the one-wave-per-tile kernel.
     Losses and gradients of every particle against the oracle."""
     monkeypatch.setenv("PYZ_FWD_LDS", str(lds))
+    monkeypatch.setenv("PYZ_FWD_LDS_MINWG", "64")       # (the default asks for 256 workgroups of 128 rows; here there are 128)
     spec = o_mlp.MLPSpec((128, 224, 10), ("relu", "softmax"), "scce")
     rng = np.random.default_rng(77)
     x = rng.normal(size=(400, 128)).astype(np.float32)
