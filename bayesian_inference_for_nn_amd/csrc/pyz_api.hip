@@ -1247,13 +1247,15 @@ static int svgd_gradients_impl(pyz_mlp *m, const float *d_particles, int n_local
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_particles || !d_x || !d_y) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   if ((rc = need_grad(m, n_local))) return rc;
-  if ((rc = set_ctl(m, 0, batch, 0.0f, 0, 0, 0, st))) return rc;
+  set_ctl_lazy(m, batch, 0.0f, 0);   // the first kernel of the pass carries the step scalars
   WgradArgs u{};
   u.mode = PYZ_UPD_NONE;
   u.grad = m->grad;
   u.grad_pstride = m->D;
+  const bool fused = can_fuse(m);
+  if (fused) u.ploss = m->scal;      // per-particle losses in the weight-gradient launch (every particle's spare workgroup)
   launch_loss_backward(m, d_particles, m->D, n_local, d_x, d_y, d_row_idx, batch, m->ctl, true, u, st);
-  PYZ_LAUNCH(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, m->scal, m->nonfinite);
+  if (!fused) PYZ_LAUNCH(k_loss_finalize, dim3(n_local), dim3(64), 0, st, m->part, m->cur_nblk, m->ctl, m->scal, m->nonfinite);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }

@@ -618,6 +618,7 @@ struct WgradArgs {
   const float *tab_lr;
   long long row_stride;
   int *nonfinite;             // device counter of steps with a NaN / Inf loss (may be nullptr)
+  float *ploss;               // particle-batched gradient passes: loss[p] = (sum of particle p's row partials) / batch
   int wt;                     // write-through stores for the updated state (pyz_st)
   PrepArgs prep;              // chained runs: the workgroups past the duties workgroup assemble the NEXT step's batch
 };
@@ -768,6 +769,13 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   // not depend on the gradient, off the critical path of the tile workgroups
   if (blockIdx.x >= (unsigned)g.tiles) {  // (without a batch to prepare, ids past `tiles` + 1 only pad the launch)
     if (blockIdx.x == (unsigned)g.tiles && blockIdx.y == 0 && w == 0) pyz_step_duties(g, l);
+    if (blockIdx.x == (unsigned)g.tiles && w == 0 && g.ploss) {   // every particle's spare workgroup: its loss (k_loss_finalize)
+      const double tot = pyz_sum_partials(g.part + (long long)blockIdx.y * g.nblk, g.nblk);
+      if (l == 0) {
+        g.ploss[blockIdx.y] = (float)(tot / (double)g.ctl->batch);
+        pyz_note_loss(g.nonfinite, g.ploss[blockIdx.y]);
+      }
+    }
     if (!PLAIN && blockIdx.x > (unsigned)g.tiles && blockIdx.y == 0 && g.prep.src) {
       const int i2 = g.ctl->i + 1;
       if (i2 < g.ctl->n_run)
