@@ -1381,14 +1381,17 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       const size_t gs_lds = pyz_svgd_gs_lds_bytes();
       static bool gs_attr = false;
       if (!gs_attr) {
-        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
+        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
+        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
         gs_attr = true;
       }
+      static const int zigzag = pyz_env_int("PYZ_SVGD_GS_ZIGZAG", 1);   // alternate the row direction from launch to launch
       for (int i = -1; i < n_total; ++i) {
         ga.i = i;
         ga.part_in = pp[(i + 2) & 1];   // what launch i - 1 wrote
         ga.part_out = pp[(i + 1) & 1];
-        PYZ_LAUNCH(k_svgd_gs, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
+        if (zigzag && (i & 1) == 0) PYZ_LAUNCH(k_svgd_gs<true>, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
+        else PYZ_LAUNCH(k_svgd_gs<false>, dim3(ga.nblk), dim3(256), gs_lds, st, ga);
       }
     } else {
       for (int i = 0; i < n_local; ++i) {

@@ -1093,6 +1093,11 @@ __device__ __forceinline__ void pyz_lds_barrier() { asm volatile("s_waitcnt lgkm
 #define PYZ_GS_STAMP(slot)
 #endif
 
+// REV: the rows are requested and consumed in DESCENDING order.  Consecutive launches alternate the direction: a launch
+// then starts on the rows its predecessor touched last, i.e. on what is still in the XCD's L2 (each XCD streams a
+// 5.1 MB share of the matrix through a 4 MiB L2: always in the same direction nothing survives from launch to launch).
+// The distance partials are per row and the float64 repulsion sum only changes its order of summation.
+template <bool REV>
 __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   extern __shared__ double gs_lds[];
   PYZ_GS_STAMP(0);
@@ -1156,7 +1161,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     }
   };
 #pragma unroll
-  for (int j = 0; j < PYZ_GS_AHEAD; ++j) load_row(j);
+  for (int j = 0; j < PYZ_GS_AHEAD; ++j) load_row(REV ? 63 - j : j);
   PYZ_GS_STAMP(1);
   // -- the K row of particle i, while the first rows are on their way (its partials were requested first)
   double kd[64];
@@ -1193,8 +1198,10 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
 #pragma unroll
   for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    if (j + PYZ_GS_AHEAD < 64) load_row(j + PYZ_GS_AHEAD);
+  for (int jo = 0; jo < 64; ++jo) {
+    constexpr int dummy_ = 0; (void)dummy_;
+    const int j = REV ? 63 - jo : jo;   // (compile-time after unrolling)
+    if (jo + PYZ_GS_AHEAD < 64) load_row(REV ? 63 - (jo + PYZ_GS_AHEAD) : jo + PYZ_GS_AHEAD);
     double a = 0.0;
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
