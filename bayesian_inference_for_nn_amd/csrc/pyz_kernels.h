@@ -1020,10 +1020,14 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
   float xf[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) xf[j] = g.all[(long long)min(j, g.M - 1) * g.D + d];
-  double xj[64];
+  // (kept as float32 and widened at every use: 64 registers instead of 192 -- twice the waves per SIMD for a kernel that
+  // waits on its five per-row operands)
 #pragma unroll
-  for (int j = 0; j < 64; ++j) xj[j] = j < g.M ? (double)xf[j] : 0.0;
+  for (int j = 0; j < 64; ++j) xf[j] = j < g.M ? xf[j] : 0.0f;
   const double two_gamma = 2.0 * (gamma_dev ? gamma_dev[0] : (double)g.gamma);
+  // (Requesting the five per-row operands of four rows together, or of the next row ahead of the FMAs, made the kernel
+  // SLOWER: 134 and 149 us against 92 -- the row loop lives on its 64 kernel values arriving as SGPR operands, and more
+  // live vector state pushes them out.)
   for (int il = 0; il < g.n_local; ++il) {
     const int i = g.row0 + il;
     const double *kr = kmat + il * 64;
@@ -1035,7 +1039,7 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
     const double xid = (double)xi;
     double r4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 64; ++j) r4[j & 3] += kr[j] * xj[j];
+    for (int j = 0; j < 64; ++j) r4[j & 3] += kr[j] * (double)xf[j];
     double rep = xid * ksumd[il] - ((r4[0] + r4[1]) + (r4[2] + r4[3]));
     rep *= two_gamma;
     const long long o = (long long)il * g.D + d;
