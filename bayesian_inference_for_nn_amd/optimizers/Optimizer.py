@@ -243,8 +243,9 @@ class Optimizer(ABC):
 
     # steps in the first chunk of a resident run, growth from chunk to chunk, largest chunk: laying out a step's batch
     # costs the host about 15 us (one permutation per epoch), the device takes 24 us for it at C2 -- a chunk may be at most
-    # 1.6 times the one the device is working through, or the device waits for its plan
-    _resident_chunks = (128, 1.5, 512)
+    # 1.6 times the one the device is working through, or the device waits for its plan; the first chunk is small because
+    # the device idles while it is planned
+    _resident_chunks = (32, 1.5, 512)
 
     def _run_resident_chunks(self, nb_iterations: int, launch):
         """A device-resident run, planned and launched in chunks: the host lays out the batches of the next chunk
