@@ -1442,10 +1442,10 @@ int pyz_predict(pyz_mlp *m, const float *d_weights, int n_samples, const float *
   for (int s0 = 0; s0 < n_samples; s0 += m->max_p) {
     const int S = std::min(m->max_p, n_samples - s0);
     launch_forward(m, d_weights + (long long)s0 * m->D, m->D, S, d_x, nullptr, n, m->ctl, st);
-    PYZ_LAUNCH(k_predict_finish, dim3(cdiv(n, 256)), dim3(256), 0, st, m->act[m->L - 1],
-                       (long long)m->max_batch * C, C, softmax, S, n,
-                       d_samples ? d_samples + (long long)s0 * n * C : nullptr, d_mean, s0 > 0 ? 1 : 0,
-                       1.0f / (float)n_samples);
+    PYZ_LAUNCH(k_predict_rows, dim3(cdiv(n, 256), S), dim3(256), 0, st, m->act[m->L - 1], (long long)m->max_batch * C, C,
+               softmax, n, d_samples ? d_samples + (long long)s0 * n * C : nullptr);
+    PYZ_LAUNCH(k_predict_mean, dim3((unsigned)cdiv((long long)n * C, 256)), dim3(256), 0, st, m->act[m->L - 1],
+               (long long)m->max_batch * C, (long long)n * C, S, d_mean, s0 > 0 ? 1 : 0, 1.0f / (float)n_samples);
   }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;

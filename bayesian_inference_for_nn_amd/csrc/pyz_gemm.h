@@ -651,7 +651,9 @@ static inline bool pyz_fwd_takes_lds(const DenseArgs &g, int grid_batch, int P, 
   // 46 for the one-wave kernel, 21 - 27 against 13.5 us on the 784 -> 400 layer; removed.)
   const int NT = g.N <= 64 ? 2 : (g.N <= 128 ? 4 : 7);
   const long long wg128 = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT)) * P;
-  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && grid_batch <= lds_max_rows &&
+  // (row counts past lds_max_rows: only launches of many particles -- predict with all its draws in one launch: 3.3 ms
+  // against 4.9 for 100 draws x 10 000 rows; with two draws per launch the one-wave kernel won, 14.5 against 16.7 ms)
+  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && (grid_batch <= lds_max_rows || P >= 8) &&
          wg128 >= pyz_env_int("PYZ_FWD_LDS_MINWG", 256);
 }
 

@@ -1275,30 +1275,36 @@ __global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out) {
 // ---------------------------------------------------------------- predict
 // BayesianModel.predict (BayesianModel.py:119-128): per-sample outputs with
 // NaN -> 0 and their mean.  last = (S, max_batch, C) logits or outputs.
-__global__ void k_predict_finish(const float *last, long long pstride, int C, int softmax, int S, int n,
-                                 float *samples, float *mean, int mean_accumulate, float inv_total) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// Two launches that cover the chip (one thread per row looping over the samples left 40 workgroups with a serial
+// chain of S round trips each: 0.65 ms for 100 x 10 000 rows): k_predict_rows normalises every (sample, row) in place
+// (and into `samples`), k_predict_mean sums the samples of every output element in sample order.
+__global__ void k_predict_rows(float *last, long long pstride, int C, int softmax, int n, float *samples) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
   if (m >= n) return;
+  float *z = last + s * pstride + (long long)m * C;
+  float mx = 0.0f, lse = 0.0f;
+  if (softmax) {
+    mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.0f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    lse = mx + logf(se);
+  }
   for (int c = 0; c < C; ++c) {
-    if (!mean_accumulate) mean[(long long)m * C + c] = 0.0f;
+    float v = softmax ? expf(z[c] - lse) : z[c];
+    v = (v != v) ? 0.0f : v;
+    if (samples) samples[((long long)s * n + m) * C + c] = v;
+    z[c] = v;
   }
-  for (int s = 0; s < S; ++s) {
-    const float *z = last + s * pstride + (long long)m * C;
-    float mx = 0.0f, lse = 0.0f;
-    if (softmax) {
-      mx = z[0];
-      for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
-      float se = 0.0f;
-      for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
-      lse = mx + logf(se);
-    }
-    for (int c = 0; c < C; ++c) {
-      float v = softmax ? expf(z[c] - lse) : z[c];
-      v = (v != v) ? 0.0f : v;
-      if (samples) samples[((long long)s * n + m) * C + c] = v;
-      mean[(long long)m * C + c] += v * inv_total;
-    }
-  }
+}
+
+__global__ void k_predict_mean(const float *last, long long pstride, long long n_out, int S, float *mean, int mean_accumulate,
+                               float inv_total) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_out) return;
+  float acc = mean_accumulate ? mean[e] : 0.0f;
+  for (int s = 0; s < S; ++s) acc += last[s * pstride + e] * inv_total;
+  mean[e] = acc;
 }
 
 // n_rows independent draws of a vector Normal(loc, scale) written into columns [col0, col0 + len) of a
