@@ -331,13 +331,20 @@ __global__ void k_bbb_sample(BbbArgs g) {
   if (e0 < g.D) {
     float z[4], wv[4];
     pyz_bbb_eps(g, t, z);
+    // a scalar prior: its softplus and logarithm once per thread, not per element (three of the seven transcendental
+    // evaluations per element of this VALU-bound kernel)
+    const float sp_s = pyz_softplus(g.prior_rho), lsp_s = logf(sp_s);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long long e = e0 + j;
       wv[j] = 0.0f;
       if (e < g.D) {
         const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
-        const float sp = pyz_softplus(g.pr_vec ? g.pr_vec[e] : g.prior_rho), lsp = logf(sp);
+        float sp = sp_s, lsp = lsp_s;
+        if (g.pr_vec) {   // uniform
+          sp = pyz_softplus(g.pr_vec[e]);
+          lsp = logf(sp);
+        }
         const float mu = g.mu[e], sg = pyz_softplus(g.rho[e]);
         const float w = z[j] * sg + mu;
         wv[j] = w;
