@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   for (int q = 0; q < EPT; ++q) {
     if (!ev[q]) continue;
     if (PLAIN) {
-      g.grad[p * g.grad_pstride + ee[q]] = gv[q];
+      pyz_st(g.grad + p * g.grad_pstride + ee[q], gv[q], g.wt);
       continue;
     }
     pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q], zz[q], lr, nstep));

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
   }
   PYZ_STAMP(0, 6);
   float *op = g.out + p * g.out_pstride;
-  const int act = g.act;
+  const int act = g.act, wt = g.wt;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int nn = n0 + 32 * nt + r;
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int mm = m0 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (mm < batch) op[(long long)mm * N + nn] = pyz_act(acc[nt][i] + bias, act);
+        if (mm < batch) pyz_st(op + (long long)mm * N + nn, pyz_act(acc[nt][i] + bias, act), wt);
       }
     }
   }
@@ -614,8 +614,8 @@ static inline int pyz_cu_count() {
 
 // single-chain launches store their outputs write-through (pyz_st); PYZ_WT=0: plain stores
 static inline int pyz_wt_for(int P) {
-  static const int on = pyz_env_int("PYZ_WT", 1);
-  return (on && P == 1) ? 1 : 0;
+  static const int on = pyz_env_int("PYZ_WT", 1);   // 2: launches of any number of particles (measurement)
+  return (on == 2 || (on && P == 1)) ? 1 : 0;
 }
 
 // waves per workgroup: split the reduction until the launch covers the chip
