@@ -452,6 +452,41 @@ __global__ void __launch_bounds__(256) k_dense_fwd_lds(DenseArgs g) {
   PYZ_STAMP(0, 6);
   float *op = g.out + p * g.out_pstride;
   const int act = g.act, wt = g.wt;
+  // The tile leaves through LDS (the slabs are dead; every wave has 4 KB of its own, no barrier): a lane holds a COLUMN
+  // of a 32 x 32 sub-tile, 16 dword stores per column tile -- 112 per thread, and the store phase was 23 us of the
+  // 220 us kernel at C5, bound by their issue.  Written to LDS as they stand and read back as rows, a lane stores four
+  // consecutive columns with one 16-byte instruction: 28 per thread.  (N % 4 == 0 with 16-byte aligned output rows;
+  // otherwise the dword stores.)
+  const bool wide = (N & 3) == 0 && (g.out_pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0;
+  if (wide) {
+    __syncthreads();   // every wave is done with the slabs
+    float *tw = &As[0][0][0] + 1024 * w;
+    static_assert(2 * BK * AS >= 4 * 1024, "tile scratch");
+    const int tr = l >> 3, tc = 4 * (l & 7);   // read-back: rows tr, tr + 8, tr + 16, tr + 24, columns tc .. tc + 3
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nn = n0 + 32 * nt + r;
+      const float bias = nn < N ? wl[(long long)K * N + nn] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tw[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r] = pyz_act(acc[nt][i] + bias, act);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ro = tr + 8 * q, mm = m0 + 32 * w + ro, nc = n0 + 32 * nt + tc;
+        const float4 v = *reinterpret_cast<const float4 *>(tw + ro * 32 + tc);
+        if (mm < batch && nc < N) {   // (N % 4 == 0: a group of four columns is inside or outside as a whole)
+          float *d = op + (long long)mm * N + nc;
+          if (wt) {
+            const f32x4 vv = {v.x, v.y, v.z, v.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d), "v"(vv) : "memory");
+          } else {
+            *reinterpret_cast<float4 *>(d) = v;
+          }
+        }
+      }
+    }
+    PYZ_STAMP(0, 7);
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int nn = n0 + 32 * nt + r;
