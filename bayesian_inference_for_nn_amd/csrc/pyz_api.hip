@@ -844,7 +844,8 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_row_idx);
     mix((unsigned long long)(uintptr_t)d_losses); mix(seed); mix((unsigned long long)bmax);
     mix((unsigned long long)(uintptr_t)m->tab_bs); mix((unsigned long long)G); mix((unsigned long long)mode);
-    mix((unsigned long long)(uintptr_t)st);
+    // (not the stream: an instantiated graph launches on any stream, and a caller that takes a fresh stream per run --
+    // torch hands them out of a pool -- would otherwise re-capture every graph on every call)
     if (swag) { mix((unsigned long long)(uintptr_t)swag->dev); mix((unsigned long long)swag->k); mix((unsigned long long)swag->freq); }
     if (m->graph_key != key) {
       drop_graphs(m);
