@@ -107,6 +107,8 @@ class BayesianModel:
         return [self.sample_model() for _ in range(n)]
 
     # ------------------------------------------------------------------ read-out
+    _predict_rows_cap = 16384      # rows per launch sequence of predict (more rows: several sequences, results joined on the device)
+
     def predict(self, x, nb_samples: int, y_true=None, loss_func=None):
         """(list of per-sample outputs, their mean); NaN outputs count as 0 (BayesianModel.py:106-129)."""
         import torch
@@ -119,7 +121,7 @@ class BayesianModel:
         # bound the activation workspace: rows x samples per launch (the plan keeps an activation and a delta buffer per
         # layer: 2 * sum(widths) floats per (sample, row)).  2^29 floats = 2 GiB of the 288: 100 draws x 10 000 rows of the
         # 784 -> 200 -> 10 model go out as ONE launch per layer (3.35 ms for the wide layer against 7 x 0.61 ms in seven)
-        rows = min(n, 16384)
+        rows = min(n, int(self._predict_rows_cap))
         per = 2 * sum(int(d) for d in self._model.dims[1:])
         chunk_s = max(1, min(nb_samples, int(os.environ.get("PYZ_PREDICT_WS", 1 << 29)) // max(1, rows * per)))
         if self._plan is None or self._plan.max_batch < rows or self._plan.max_particles < chunk_s:

@@ -2,6 +2,8 @@
 (compile / train / step / result / predict) driven through the HIP kernels, checked against
 the CPU oracle where a deterministic comparison exists."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -220,6 +222,20 @@ def test_bayesian_model_predict_matches_oracle():
     np.testing.assert_allclose(np.stack(samples), rs, atol=1e-5)
     np.testing.assert_allclose(mean, rm, atol=1e-5)
     assert np.array_equal(np.argmax(mean, axis=1), np.argmax(rm, axis=1))          # integer class labels bit-exact
+    # more rows than one launch sequence takes (and fewer samples per launch than asked for): the pieces are joined on
+    # the device and must give the same arrays
+    bm._predict_rows_cap, bm._plan = 16, None
+    os_ws = os.environ.get("PYZ_PREDICT_WS")
+    os.environ["PYZ_PREDICT_WS"] = str(16 * 2 * (12 + 3) * 4)                      # four samples per launch
+    try:
+        samples2, mean2 = bm.predict(x, nb_samples=6)
+    finally:
+        if os_ws is None:
+            del os.environ["PYZ_PREDICT_WS"]
+        else:
+            os.environ["PYZ_PREDICT_WS"] = os_ws
+    np.testing.assert_array_equal(np.stack(samples2), np.stack(samples))
+    np.testing.assert_array_equal(np.asarray(mean2), np.asarray(mean))
 
 
 def test_compat_standins_run_a_reference_style_driver():
