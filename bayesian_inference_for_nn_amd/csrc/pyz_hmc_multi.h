@@ -47,16 +47,18 @@ static inline size_t pyz_hmc_multi_lds_bytes(int max_rows, int MI, int MC, int C
   return ((fl * 4 + 15) / 16) * 16 + 64 * sizeof(double);
 }
 
-// element e of the summed gradient: the NW slabs in slice order; the loads go out eight at a time (one
-// load per round trip would put NW dependent L2 latencies in front of every launch)
+// element e of the summed gradient: the NW slabs in slice order; the loads go out sixteen at a time (one
+// load per round trip would put NW dependent latencies in front of every launch; the slabs were written by the
+// previous launch on other XCDs, so a round trip goes to the Infinity Cache: with 16 slices per chain the sum
+// is ONE round trip instead of two)
 __device__ __forceinline__ float pyz_hm_slab_sum(const float *sl, const int NW, const int D, const int e) {
   float gs = 0.0f;
-  for (int k0 = 0; k0 < NW; k0 += 8) {
-    float v[8];
+  for (int k0 = 0; k0 < NW; k0 += 16) {
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = k0 + j < NW ? sl[(long long)(k0 + j) * D + e] : 0.0f;
+    for (int j = 0; j < 16; ++j) v[j] = sl[(long long)min(k0 + j, NW - 1) * D + e];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) gs += v[j];
+    for (int j = 0; j < 16; ++j) gs += k0 + j < NW ? v[j] : 0.0f;
   }
   return gs;
 }
