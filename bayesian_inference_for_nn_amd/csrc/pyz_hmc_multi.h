@@ -88,6 +88,22 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi(HmcMultiArgs m) {
   const size_t fl = (size_t)(3 + PYZ_HM_WAVES) * D + (size_t)64 * (MI + MC + 2) + (size_t)m.max_rows * MI +
                     (size_t)m.max_rows * MC + (size_t)m.max_rows * (a.loss == PYZ_LOSS_MSE ? C : 1);
   double *sm = reinterpret_cast<double *>(lds + ((fl * 4 + 15) / 16) * 4);
+  // ---- the state of step t (every workgroup computes the same values; workgroup 0 stores them).  Its operands were
+  // written by the previous launch on other XCDs (a round trip to the Infinity Cache): this thread's first element
+  // is requested BEFORE the data slice is staged, so that the two round trips overlap instead of following each other
+  const long long so = (long long)chain * D;
+  float *q_out = m.qw + ((long long)(m.t & 1) * P) * D + so, *p_out = m.pw + ((long long)(m.t & 1) * P) * D + so;
+  const int pb0 = (m.t - 1) & 1;
+  const float *sl0 = m.slab + (((long long)pb0 * P + chain) * NW) * D;
+  float pre_q = 0.0f, pre_p = 0.0f, pre_v[16];
+  const bool pre_on = m.t > 0 && NW <= 16;   // uniform
+  if (pre_on) {
+    const int e = min(t, D - 1);
+    pre_q = m.qw[((long long)pb0 * P) * D + so + e];
+    pre_p = m.pw[((long long)pb0 * P) * D + so + e];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pre_v[j] = sl0[(long long)min(j, NW - 1) * D + e];
+  }
   // ---- this slice of the data set
   for (int e = t; e < nloc * MI; e += PYZ_HM_THREADS) {
     const int r = e / MI, i = e - r * MI;
@@ -98,9 +114,6 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi(HmcMultiArgs m) {
   } else {
     for (int e = t; e < nloc * C; e += PYZ_HM_THREADS) yf[e] = reinterpret_cast<const float *>(a.y)[(long long)r0 * C + e];
   }
-  // ---- the state of step t (every workgroup computes the same values; workgroup 0 stores them)
-  const long long so = (long long)chain * D;
-  float *q_out = m.qw + ((long long)(m.t & 1) * P) * D + so, *p_out = m.pw + ((long long)(m.t & 1) * P) * D + so;
   if (m.t == 0) {
     double sp2 = 0.0, slp = 0.0;
     const float ls = logf(a.prior_sigma);
@@ -131,15 +144,25 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi(HmcMultiArgs m) {
     const float eps = a.epsilon, drift = eps / a.m, n_train = (float)N;
     const float isig2 = 1.0f / (a.prior_sigma * a.prior_sigma);
     for (int e = t; e < D; e += PYZ_HM_THREADS) {
-      const float gs = pyz_hm_slab_sum(sl, NW, D, e);
-      const float qv = q_in[e];
+      float gs, qv, pin;
+      if (pre_on && e == t) {   // the element requested ahead (same values, same order of summation)
+        gs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gs += j < NW ? pre_v[j] : 0.0f;
+        qv = pre_q;
+        pin = pre_p;
+      } else {
+        gs = pyz_hm_slab_sum(sl, NW, D, e);
+        qv = q_in[e];
+        pin = p_in[e];
+      }
       const float dU = (qv - a.prior_mean) * isig2 + n_train * gs;
       float pv, qn;
       if (m.t == 1) {  // behind the first gradient: half kick (HMC.py:82), then the first drift
-        pv = p_in[e] - (eps / 2) * dU;
+        pv = pin - (eps / 2) * dU;
         qn = qv + drift * pv;
       } else {         // kick + drift (HMC.py:84-86)
-        pv = p_in[e] - eps * dU;
+        pv = pin - eps * dU;
         qn = qv + drift * pv;
       }
       q[e] = qn;
