@@ -1301,6 +1301,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
   const size_t lds = sizeof(double) * (size_t)(5 * n_total);
   const int jgroups = cdiv(n_total, 8);
   const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);  // read per call: tests flip it
+  bool loss_done = false;   // the step's loss written by a kernel of the sweep itself (else k_svgd_loss at the end)
   const bool tile_ok = sweep == PYZ_SWEEP_JACOBI && n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles;
   if (median && !(tile_ok && n_total % 4 == 0))
     return pyz_fail(PYZ_E_INVALID, "the median-heuristic bandwidth needs the Jacobi sweep on a snapshot, at most 64 particles, "
@@ -1354,6 +1355,9 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       ta.dmat = td.dmat;
       ta.gamma_dev = td.gamma_dev;
     }
+    ta.loss_in = loss;
+    ta.loss_out = d_loss;
+    loss_done = true;
     PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta, 0);
     PYZ_LAUNCH(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum,
                (const double *)ta.ksumd, (const double *)ta.gamma_dev);
@@ -1402,7 +1406,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       }
     }
   }
-  PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
+  if (!loss_done) PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }

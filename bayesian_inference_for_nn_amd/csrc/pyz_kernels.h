@@ -718,6 +718,10 @@ struct SvgdTileArgs {
   // median-heuristic bandwidth (SVGD.py:165-181) only: the squared distances of ALL pairs and the bandwidth they give
   double *dmat;            // (M, 64) squared distances (0 past M), or nullptr
   double *gamma_dev;       // [1] gamma = 1 / (2 h^2) = log(M + 1) / median(d), or nullptr: the fixed `gamma`
+  // the step's loss rides in k_svgd_kmat (its launch is 4 - 5 us for one thread's work as a kernel of its own):
+  // loss_out[0] = sum_i loss_in[i] / M over the local particles (k_svgd_loss), or nullptr
+  const float *loss_in;
+  float *loss_out;
 };
 
 __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
@@ -926,6 +930,12 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
 __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
   __shared__ double sl[4][64], sg[4][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  if (g.loss_out && !dist_only && blockIdx.x == 0 && q == 3) {   // the last wave of block 0: k_svgd_loss's arithmetic, same
+    const float mine = j < g.n_local ? g.loss_in[j] / (float)g.M : 0.0f;   // order; the loads in one round trip
+    float s = 0.0f;
+    for (int i = 0; i < g.n_local; ++i) s += __shfl(mine, i, 64);
+    if (j == 0) g.loss_out[0] = s;
+  }
   double d;
   if (g.dmat && !dist_only) {
     if (q != 0) return;
