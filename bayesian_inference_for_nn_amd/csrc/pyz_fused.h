@@ -806,6 +806,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   long long ee[EPT];
   bool ev[EPT];
   float th0[PLAIN ? 1 : EPT], mu0[PLAIN ? 1 : EPT], sq0[PLAIN ? 1 : EPT], zz[PLAIN ? 1 : EPT];
+  float zg[PLAIN ? 1 : EPT];   // generated noise: its own registers (writing a register a load may still be filling waits for EVERY load in flight)
   auto prefetch = [&]() {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -822,7 +823,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       ev[q] = ii <= K && nn < N;
       ee[q] = w_off + (long long)min(ii, K) * N + min(nn, N - 1);
       if (PLAIN) continue;
-      th0[q] = mu0[q] = sq0[q] = zz[q] = 0.0f;
+      th0[q] = mu0[q] = sq0[q] = zz[q] = zg[q] = 0.0f;
       if (mode != PYZ_UPD_NONE) th0[q] = g.theta[ee[q]];
       if (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB || mode == PYZ_UPD_SWAG) {
         mu0[q] = g.mean[ee[q]];
@@ -833,11 +834,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
     if (!PLAIN && (mode == PYZ_UPD_SGLD || mode == PYZ_UPD_BBB) && !g.unit_noise) {
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
-        const float4 nq = mode == PYZ_UPD_SGLD
-                              ? pyz_normal4(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)(ee[q] >> 2))
-                              : pyz_normal4(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)(ee[q] >> 2));
-        const int k = (int)(ee[q] & 3);
-        zz[q] = k == 0 ? nq.x : (k == 1 ? nq.y : (k == 2 ? nq.z : nq.w));
+        zg[q] = mode == PYZ_UPD_SGLD ? pyz_normal1(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)ee[q])
+                                     : pyz_normal1(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)ee[q]);
       }
     }
   };
@@ -906,7 +904,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       pyz_st(g.grad + p * g.grad_pstride + ee[q], gv[q], g.wt);
       continue;
     }
-    pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q], zz[q], lr, nstep));
+    pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q],
+                                                               PLAIN ? 0.0f : (g.unit_noise ? zz[q] : zg[q]), lr, nstep));
   }
   PYZ_STAMP(2, 3);
 }

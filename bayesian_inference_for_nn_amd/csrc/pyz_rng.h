@@ -47,3 +47,17 @@ __device__ __forceinline__ float4 pyz_normal4(uint64_t seed, uint32_t stream, ui
   sincospif(2.0f * pyz_unit(r.w), &sb, &cb);
   return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
 }
+
+// the standard normal of ONE element e (= component e % 4 of pyz_normal4 for idx4 = e / 4, bit for bit): the words of the
+// element's pair are selected before the Box-Muller step, so there is one logarithm / square root / sincos instead of
+// two and no branch on e % 4 (a divergent branch inside a latency-hiding hook makes the compiler wait for every load in flight)
+__device__ __forceinline__ float pyz_normal1(uint64_t seed, uint32_t stream, uint32_t step, uint64_t e) {
+  const uint64_t idx4 = e >> 2;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)idx4, (uint32_t)(idx4 >> 32), step, stream),
+                                make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const bool second = (e & 2) != 0, odd = (e & 1) != 0;
+  const float rad = sqrtf(-2.0f * logf(pyz_unit(second ? r.z : r.x)));
+  float sn, cs;
+  sincospif(2.0f * pyz_unit(second ? r.w : r.y), &sn, &cs);
+  return rad * (odd ? sn : cs);
+}

@@ -39,5 +39,5 @@ with torch.cuda.stream(st):
 step_us = dt / 2048 * 1e6
 us = [round(v[1], 2) for v in kp.by_kernel().values()]
 print(json.dumps({"label": label, "us_per_step": round(step_us, 2), "steps_per_s": round(1e6 / step_us),
-                  "kernels_us": us, "loss": round(float(losses[n - 1].item()), 5),
+                  "kernels_us": us, "loss": round(float(losses[n - 1].item()), 5), "theta_bits_sum": int(theta.view(torch.int32).to(torch.int64).sum().item()),
                   "env": {k_: v for k_, v in os.environ.items() if k_.startswith("PYZ_")}}), flush=True)
