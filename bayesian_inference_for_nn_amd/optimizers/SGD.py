@@ -70,7 +70,7 @@ class SGD(Optimizer):
         freq = int(self._frequency)
         hits = [s for s in range(nb_iterations) if (self._n + s) % freq == 0]
         cut = hits[-1] + 1 if hits else 0             # steps [0, cut) end with the last "mean <- weights"
-        stream = torch.cuda.Stream()
+        stream = self._run_stream()
         stream.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(stream):
@@ -83,7 +83,7 @@ class SGD(Optimizer):
             if cut > 0:
                 raise
             return False
-        torch.cuda.current_stream().wait_stream(stream)
+        self._join_run(stream)
         # epoch bookkeeping of step() (SGD.py:45-60) for the steps just run
         last_epoch = self._plan_epoch_starts[-1] if self._plan_epoch_starts else None
         if last_epoch is None:
