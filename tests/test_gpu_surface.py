@@ -96,6 +96,10 @@ def test_sgld_surface_matches_oracle_and_resident_training():
     b2.compile(hyp, MOONS_JSON, ds, verbose=False, seed=7)
     a._resident_chunks = (40, 0.5, 40)                          # planned and launched as 40 + 20 + 10 steps
     a.train(70)
+    # train() is synchronous like the reference's loop: the HOST has joined the run stream when it returns (a wait of
+    # the caller's stream enqueued behind the run instead slows every step of the run, Optimizer._join_run)
+    assert a._res_stream.query(), "train() returned with its run still in flight"
+    stream_of_first_call = a._res_stream
     b2._nb_iterations = 70
     b2._init_sgld_lr()
     for _ in range(70):
@@ -103,6 +107,8 @@ def test_sgld_surface_matches_oracle_and_resident_training():
     ta, tb = a._theta.cpu().numpy(), b2._theta.cpu().numpy()
     np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-5 * np.abs(tb).max())
     assert a._n == 70 and abs(float(a._running_dev.item()) - float(b2._running_dev.item())) < 1e-3
+    a.train(10)
+    assert a._res_stream is stream_of_first_call and a._res_stream.query()   # one run stream per optimizer
 
 
 def test_hmc_surface_bookkeeping_and_nan_prior():
