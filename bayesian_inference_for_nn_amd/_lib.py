@@ -55,6 +55,8 @@ SIGNATURES = {
                                 C.c_int, _p, _p]),
     "pyz_svgd_gradients": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, _p]),
     "pyz_svgd_sweep": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _f, _f, _i64, C.c_int, _p, _p]),
+    "pyz_svgd_kernel_matrix": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _f, _p]),
+    "pyz_svgd_combine": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _f, _f, _i64, _p, _p]),
     "pyz_predict": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p, _p, _p]),
     "pyz_sample_normal_rows": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _u64, _u32, _u32, _p]),
     "pyz_fill_normal": (C.c_int, [_p, _i64, _u64, _u32, _u32, _f, _f, _p]),

@@ -8,6 +8,7 @@
 #include "pyz_common.h"
 #include "pyz_fused.h"
 #include "pyz_gemm.h"
+#include "pyz_gemm_ring.h"
 #include "pyz_hmc_fused.h"
 #include "pyz_hmc_multi.h"
 #include "pyz_kernels.h"
@@ -73,6 +74,7 @@ void drop_graphs(pyz_mlp *m) {
 }
 
 int need_grad(pyz_mlp *m, int P) {
+  m->grad_owner = 2;   // (pyz_svgd_gradients sets 1 after this call)
   return ensure_bytes((void **)&m->grad, &full(m)->x.grad_cap, sizeof(float) * (size_t)P * m->D + 64, m);
 }
 int need_grad2(pyz_mlp *m, int P) {
@@ -84,7 +86,8 @@ int need_qsave(pyz_mlp *m, int P) {
 int need_part(pyz_mlp *m, size_t n_doubles) {
   return ensure_bytes((void **)&m->part, &full(m)->x.part_cap, sizeof(double) * n_doubles, m);
 }
-int need_part2(pyz_mlp *m, size_t n_doubles) {
+int need_part2(pyz_mlp *m, size_t n_doubles, bool keep_kernel_matrix = false) {
+  if (!keep_kernel_matrix) m->km_valid = false;   // the float64 scratch is about to be rewritten
   return ensure_bytes((void **)&full(m)->x.part2, &full(m)->x.part2_cap, sizeof(double) * n_doubles, m);
 }
 
@@ -164,6 +167,7 @@ void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, c
   for (int l = 0; l < l_end; ++l) {
     DenseArgs g = forward_args(m, l, theta, theta_ps, x, row_idx, ctl, gather_out);
     g.wt = pyz_wt_for(P);
+    if (pyz_launch_fwd_ring(g, grid_batch, P, st)) continue;   // mid-size launches: 32-row blocks through the LDS-DMA ring
     if (!g.row_idx && !g.init_on && !g.gather_out) g.rows_cap = std::min(grid_batch, m->max_batch);   // (layer 0 of a caller-owned x: its rows cover grid_batch by contract)
     pyz_launch_fwd(g, grid_batch, P, st);
   }
@@ -526,6 +530,14 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
   {
     const int rc = need_part(m, (size_t)max_particles * max_batch + 8);  // up to one loss partial per row (k_head_rows)
     if (rc != PYZ_OK) return fail(rc);
+  }
+  // kernels with more than 64 KB of dynamic LDS: the allowance is a per-device attribute of the function, set here for the
+  // device this plan lives on (one process may drive several devices, each through plans of its own)
+  {
+    const int gs_lds = (int)pyz_svgd_gs_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs) failed"));
   }
   *out = m;
   return PYZ_OK;
@@ -1005,7 +1017,7 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_q || !d_x || !d_y || !d_stats || !h_uniform) return pyz_fail(PYZ_E_INVALID, "null pointer");
   if (L < 0) return pyz_fail(PYZ_E_INVALID, "L must be >= 0");
-  if ((rc = need_grad(m, P)) || (rc = need_grad2(m, P)) || (rc = need_qsave(m, P))) return rc;
+  if ((rc = need_grad(m, P)) || (rc = need_grad2(m, P)) || (rc = need_qsave(m, P))) return rc;   // (also: the gradients of an SVGD phase 1 are gone)
   const int nblk4 = cdiv(cdiv(m->D, 4), 256), nblk1 = cdiv(m->D, 256);
   if ((rc = need_part2(m, (size_t)P * 2 * nblk1 + 8))) return rc;
   hipStream_t st = as_stream(stream);
@@ -1248,6 +1260,8 @@ static int svgd_gradients_impl(pyz_mlp *m, const float *d_particles, int n_local
   if ((rc = check_loss_combo(m))) return rc;
   if (!d_particles || !d_x || !d_y) return pyz_fail(PYZ_E_INVALID, "null device pointer");
   if ((rc = need_grad(m, n_local))) return rc;
+  m->grad_owner = 1;
+  m->grad_rows = n_local;
   set_ctl_lazy(m, batch, 0.0f, 0);   // the first kernel of the pass carries the step scalars
   WgradArgs u{};
   u.mode = PYZ_UPD_NONE;
@@ -1261,23 +1275,163 @@ static int svgd_gradients_impl(pyz_mlp *m, const float *d_particles, int n_local
   return PYZ_OK;
 }
 
+// ---- phase 2 on a snapshot, all rows at once (Jacobi; M <= 64, local rows in multiples of four), in two halves:
+//   kernel matrix   the squared distances of the local rows against the snapshot (Gram matrix on the float64 matrix
+//                   cores, or pairwise), [the median-heuristic bandwidth,] K rows and their sums -- a function of the
+//                   snapshot ALONE: it may run on a second stream while phase 1 computes the gradients;
+//   combine         phi, the legacy Adam step and the step's loss for every local row -- needs both.
+// Both carve the same layout out of the plan's float64 scratch.
+struct TileLayout {
+  SvgdTileArgs ta;   // the local rows
+  SvgdTileArgs td;   // the distance pass (all rows under the median heuristic)
+};
+
+static bool svgd_tile_shape(int n_local, int n_total, int row0, const float *d_all, const float *d_particles) {
+  return n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles;
+}
+
+static int svgd_tile_layout(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma, TileLayout &L) {
+  const bool median = gamma == PYZ_SVGD_GAMMA_MEDIAN;
+  SvgdTileArgs ta{};
+  ta.all = d_all;
+  ta.D = m->D;
+  ta.M = n_total;
+  ta.n_local = n_local;
+  ta.row0 = row0;
+  ta.gamma = gamma;
+  ta.range = PYZ_SV_E * cdiv(m->D, 256LL * PYZ_SV_E);  // one round of workgroups on the 256 CUs
+  ta.nblk = cdiv(m->D, ta.range);
+  // the median heuristic (SVGD.py:165-181) needs the squared distances of ALL pairs: the distance pass then covers
+  // every row of the gathered matrix on every rank (the matrix is read once either way)
+  const int dist_rows = median ? n_total : n_local, dist_row0 = median ? 0 : row0;
+  const size_t n_part = (size_t)dist_rows * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
+  const size_t n_dmat = median ? (size_t)n_total * 64 + 8 : 0;
+  const int rc = need_part2(m, n_part + n_k + 2 * (size_t)n_local + n_diag + n_dmat + 16, /*keep_kernel_matrix=*/true);
+  if (rc) return rc;
+  ta.part = full(m)->x.part2;
+  ta.kmat = ta.part + n_part;
+  ta.ksumd = ta.kmat + n_k;
+  ta.ksum = reinterpret_cast<float *>(ta.ksumd + n_local);
+  double *after_ksum = ta.ksumd + n_local + (n_local + 1) / 2 + 1;
+  SvgdTileArgs td = ta;
+  td.n_local = dist_rows;
+  td.row0 = dist_row0;
+  td.diag = after_ksum;                        // (only read when the Gram form ran: see the kernel-matrix half)
+  if (median) {
+    td.dmat = after_ksum + n_diag;             // (M, 64) squared distances, then the bandwidth
+    td.gamma_dev = td.dmat + (size_t)n_total * 64;
+    ta.dmat = td.dmat;
+    ta.gamma_dev = td.gamma_dev;
+  }
+  L.ta = ta;
+  L.td = td;
+  return PYZ_OK;
+}
+
+static int svgd_check_rows(const pyz_mlp *m, int n_local, int n_total, int row0, float gamma) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (n_local <= 0 || n_local > m->max_p) return pyz_fail(PYZ_E_SHAPE, "particle count %d outside [1, %d] of the plan", n_local, m->max_p);
+  if (n_total < n_local || row0 < 0 || row0 + n_local > n_total) return pyz_fail(PYZ_E_INVALID, "rows [%d, %d) outside the %d particles", row0, row0 + n_local, n_total);
+  if (n_total > 1024) return pyz_fail(PYZ_E_INVALID, "more than 1024 particles");
+  if (gamma != PYZ_SVGD_GAMMA_MEDIAN && !(gamma > 0.0f)) return pyz_fail(PYZ_E_INVALID, "gamma must be positive (or PYZ_SVGD_GAMMA_MEDIAN)");
+  return PYZ_OK;
+}
+
+static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma, hipStream_t st) {
+  int rc = svgd_check_rows(m, n_local, n_total, row0, gamma);
+  if (rc) return rc;
+  if (!d_all) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  const bool median = gamma == PYZ_SVGD_GAMMA_MEDIAN;
+  if (!svgd_tile_shape(n_local, n_total, row0, d_all, nullptr) || (median && n_total % 4 != 0))
+    return pyz_fail(PYZ_E_INVALID, "the kernel matrix of a snapshot needs at most 64 particles and local rows [row0, row0 + n) in "
+                                   "multiples of four (the median heuristic: the particle count too)");
+  m->km_valid = false;
+  TileLayout L;
+  if ((rc = svgd_tile_layout(m, d_all, n_total, row0, n_local, gamma, L))) return rc;
+  // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
+  // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
+  const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
+  const bool gram = gram_on && mfma_f64_layout_ok(st);
+  if (gram) {
+    PYZ_LAUNCH(k_svgd_gram_tile, dim3(L.td.nblk), dim3(256), 0, st, L.td);
+  } else {
+    L.td.diag = nullptr;
+    PYZ_LAUNCH(k_svgd_dist_tile, dim3(L.td.nblk), dim3(256), 0, st, L.td);
+  }
+  L.ta.diag = L.td.diag;
+  if (median) {
+    PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(256), 0, st, L.td, 1);   // distances only
+    PYZ_LAUNCH(k_svgd_median, dim3(1), dim3(1024), 0, st, L.td);
+  }
+  PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, L.ta, 0);
+  PYZ_LAUNCH_CHECK();
+  m->km_valid = true;
+  m->km_all = d_all;
+  m->km_total = n_total;
+  m->km_row0 = row0;
+  m->km_local = n_local;
+  m->km_gamma = gamma;
+  return PYZ_OK;
+}
+
+static int svgd_check_gradients(const pyz_mlp *m, int n_local) {
+  if (!m->grad || m->grad_owner != 1 || m->grad_rows != n_local)
+    return pyz_fail(PYZ_E_INVALID, "no gradients of these %d particles in the plan: pyz_svgd_gradients must be the last "
+                                   "gradient-producing call on it", n_local);
+  return PYZ_OK;
+}
+
+static int svgd_combine_impl(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                             float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, float *d_loss, hipStream_t st) {
+  int rc = svgd_check_rows(m, n_local, n_total, row0, gamma);
+  if (rc) return rc;
+  if (!d_particles || !d_all || !d_adam_m || !d_adam_v || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (t < 1) return pyz_fail(PYZ_E_INVALID, "Adam step t must be >= 1");
+  if ((rc = svgd_check_gradients(m, n_local))) return rc;
+  if (!m->km_valid || m->km_all != d_all || m->km_total != n_total || m->km_row0 != row0 || m->km_local != n_local || m->km_gamma != gamma)
+    return pyz_fail(PYZ_E_INVALID, "pyz_svgd_combine without the kernel matrix of this snapshot (pyz_svgd_kernel_matrix with the "
+                                   "same d_all, rows and gamma must precede it, with no other call on the plan's scratch in between)");
+  TileLayout L;
+  if ((rc = svgd_tile_layout(m, d_all, n_total, row0, n_local, gamma, L))) return rc;
+  SvgdTileArgs &ta = L.ta;
+  ta.particles = d_particles;
+  ta.adam_m = d_adam_m;
+  ta.adam_v = d_adam_v;
+  ta.grad = m->grad;
+  const double b1t = std::pow(0.9, (double)t), b2t = std::pow(0.999, (double)t);
+  ta.lr_t = (float)((double)lr * std::sqrt(1.0 - b2t) / (1.0 - b1t));
+  ta.loss_in = m->scal;   // [n_local], written by phase 1
+  ta.loss_out = d_loss;
+  PYZ_LAUNCH(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum,
+             (const double *)ta.ksumd, (const double *)ta.gamma_dev);
+  PYZ_LAUNCH_CHECK();
+  m->km_valid = false;     // consumed (the next step has another snapshot)
+  return PYZ_OK;
+}
+
 // phase 2: kernel row(s), repulsion, Adam (SVGD.py:54-68,112-123) on the gradients phase 1 left
 static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
                            float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, int sweep, float *d_loss,
                            hipStream_t st) {
-  int rc;
-  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
-  if (n_local <= 0 || n_local > m->max_p) return pyz_fail(PYZ_E_SHAPE, "particle count %d outside [1, %d] of the plan", n_local, m->max_p);
+  int rc = svgd_check_rows(m, n_local, n_total, row0, gamma);
+  if (rc) return rc;
   if (!d_particles || !d_all || !d_adam_m || !d_adam_v || !d_loss) return pyz_fail(PYZ_E_INVALID, "null device pointer");
-  if (n_total < n_local || row0 < 0 || row0 + n_local > n_total) return pyz_fail(PYZ_E_INVALID, "rows [%d, %d) outside the %d particles", row0, row0 + n_local, n_total);
   if (t < 1) return pyz_fail(PYZ_E_INVALID, "Adam step t must be >= 1");
   const bool median = gamma == PYZ_SVGD_GAMMA_MEDIAN;
-  if (!median && !(gamma > 0.0f)) return pyz_fail(PYZ_E_INVALID, "gamma must be positive (or PYZ_SVGD_GAMMA_MEDIAN)");
   if (sweep != PYZ_SWEEP_GAUSS_SEIDEL && sweep != PYZ_SWEEP_JACOBI) return pyz_fail(PYZ_E_INVALID, "unknown sweep %d", sweep);
   if (sweep == PYZ_SWEEP_GAUSS_SEIDEL && (d_all != d_particles || n_local != n_total))
     return pyz_fail(PYZ_E_INVALID, "the Gauss-Seidel sweep needs the whole particle matrix on this device");
-  if (n_total > 1024) return pyz_fail(PYZ_E_INVALID, "more than 1024 particles");
-  if (!m->grad) return pyz_fail(PYZ_E_INVALID, "pyz_svgd_sweep without a preceding pyz_svgd_gradients");
+  if ((rc = svgd_check_gradients(m, n_local))) return rc;
+  const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);  // read per call: tests flip it
+  const bool tile_ok = sweep == PYZ_SWEEP_JACOBI && svgd_tile_shape(n_local, n_total, row0, d_all, d_particles);
+  if (median && !(tile_ok && n_total % 4 == 0))
+    return pyz_fail(PYZ_E_INVALID, "the median-heuristic bandwidth needs the Jacobi sweep on a snapshot, at most 64 particles, "
+                                   "and particle / local-row counts in multiples of four");
+  if (tile_ok && (tiles_on || median)) {
+    // every row from the same snapshot: the particle matrix is read once per pass (k_svgd_*_tile)
+    if ((rc = svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, st))) return rc;
+    return svgd_combine_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, d_loss, st);
+  }
   const int nblk = cdiv(m->D, PYZ_SVGD_BLOCK_ELEMS);  // one float64 partial per workgroup of k_svgd_dist
   const int rows_at_once = sweep == PYZ_SWEEP_JACOBI ? n_local : 1;
   if ((rc = need_part2(m, (size_t)rows_at_once * nblk * n_total + 8))) return rc;
@@ -1300,68 +1454,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
   a.nblk = nblk;
   const size_t lds = sizeof(double) * (size_t)(5 * n_total);
   const int jgroups = cdiv(n_total, 8);
-  const int tiles_on = pyz_env_int("PYZ_SVGD_TILES", 1);  // read per call: tests flip it
-  bool loss_done = false;   // the step's loss written by a kernel of the sweep itself (else k_svgd_loss at the end)
-  const bool tile_ok = sweep == PYZ_SWEEP_JACOBI && n_total <= 64 && row0 % 4 == 0 && n_local % 4 == 0 && d_all != d_particles;
-  if (median && !(tile_ok && n_total % 4 == 0))
-    return pyz_fail(PYZ_E_INVALID, "the median-heuristic bandwidth needs the Jacobi sweep on a snapshot, at most 64 particles, "
-                                   "and particle / local-row counts in multiples of four");
-  if (tile_ok && (tiles_on || median)) {
-    // every row from the same snapshot: the particle matrix is read once per pass (k_svgd_*_tile)
-    SvgdTileArgs ta{};
-    ta.particles = d_particles;
-    ta.all = d_all;
-    ta.adam_m = d_adam_m;
-    ta.adam_v = d_adam_v;
-    ta.grad = m->grad;
-    ta.D = m->D;
-    ta.M = n_total;
-    ta.n_local = n_local;
-    ta.row0 = row0;
-    ta.lr_t = a.lr_t;
-    ta.gamma = gamma;
-    ta.range = PYZ_SV_E * cdiv(m->D, 256LL * PYZ_SV_E);  // one round of workgroups on the 256 CUs
-    ta.nblk = cdiv(m->D, ta.range);
-    // the median heuristic (SVGD.py:165-181) needs the squared distances of ALL pairs: the distance pass then covers
-    // every row of the gathered matrix on every rank (the matrix is read once either way)
-    const int dist_rows = median ? n_total : n_local, dist_row0 = median ? 0 : row0;
-    const size_t n_part = (size_t)dist_rows * ta.nblk * 64, n_k = (size_t)n_local * 64, n_diag = (size_t)ta.nblk * 64;
-    const size_t n_dmat = median ? (size_t)n_total * 64 + 8 : 0;
-    if ((rc = need_part2(m, n_part + n_k + 2 * (size_t)n_local + n_diag + n_dmat + 16))) return rc;
-    ta.part = full(m)->x.part2;
-    ta.kmat = ta.part + n_part;
-    ta.ksumd = ta.kmat + n_k;
-    ta.ksum = reinterpret_cast<float *>(ta.ksumd + n_local);
-    double *after_ksum = ta.ksumd + n_local + (n_local + 1) / 2 + 1;
-    // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
-    // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
-    const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
-    SvgdTileArgs td = ta;  // the distance pass
-    td.n_local = dist_rows;
-    td.row0 = dist_row0;
-    if (gram_on && mfma_f64_layout_ok(st)) {
-      td.diag = after_ksum;
-      PYZ_LAUNCH(k_svgd_gram_tile, dim3(td.nblk), dim3(256), 0, st, td);
-    } else {
-      td.diag = nullptr;
-      PYZ_LAUNCH(k_svgd_dist_tile, dim3(td.nblk), dim3(256), 0, st, td);
-    }
-    ta.diag = td.diag;
-    if (median) {
-      td.dmat = after_ksum + n_diag;           // (M, 64) squared distances, then the bandwidth
-      td.gamma_dev = td.dmat + (size_t)n_total * 64;
-      PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(256), 0, st, td, 1);   // distances only
-      PYZ_LAUNCH(k_svgd_median, dim3(1), dim3(1024), 0, st, td);
-      ta.dmat = td.dmat;
-      ta.gamma_dev = td.gamma_dev;
-    }
-    ta.loss_in = loss;
-    ta.loss_out = d_loss;
-    loss_done = true;
-    PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, ta, 0);
-    PYZ_LAUNCH(k_svgd_update_tile, dim3(cdiv(m->D, 256)), dim3(256), 0, st, ta, (const double *)ta.kmat, (const float *)ta.ksum,
-               (const double *)ta.ksumd, (const double *)ta.gamma_dev);
-  } else if (sweep == PYZ_SWEEP_JACOBI) {
+  if (sweep == PYZ_SWEEP_JACOBI) {
     a.i_local = -1;
     PYZ_LAUNCH(k_svgd_dist, dim3(nblk, jgroups, n_local), dim3(256), 0, st, a);
     PYZ_LAUNCH(k_svgd_update, dim3(cdiv(m->D, 256), n_local), dim3(256), lds, st, a);
@@ -1384,12 +1477,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       if ((rc = need_part2(m, 2 * n_part + 8))) return rc;
       double *pp[2] = {full(m)->x.part2, full(m)->x.part2 + n_part};
       const size_t gs_lds = pyz_svgd_gs_lds_bytes();
-      static bool gs_attr = false;
-      if (!gs_attr) {
-        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
-        PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs_lds));
-        gs_attr = true;
-      }
+      // (k_svgd_gs's 130 KB of dynamic LDS: allowed when the plan was created, pyz_mlp_create)
       static const int zigzag = pyz_env_int("PYZ_SVGD_GS_ZIGZAG", 1);   // alternate the row direction from launch to launch
       for (int i = -1; i < n_total; ++i) {
         ga.i = i;
@@ -1406,7 +1494,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       }
     }
   }
-  if (!loss_done) PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
+  PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
@@ -1421,6 +1509,16 @@ int pyz_svgd_sweep(pyz_mlp *m, float *d_particles, int n_local, const float *d_a
                    void *stream) {
   return svgd_sweep_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, sweep, d_loss,
                          as_stream(stream));
+}
+
+int pyz_svgd_kernel_matrix(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma, void *stream) {
+  return svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, as_stream(stream));
+}
+
+int pyz_svgd_combine(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                     float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, float *d_loss, void *stream) {
+  return svgd_combine_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, d_loss,
+                           as_stream(stream));
 }
 
 int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
@@ -1525,7 +1623,9 @@ int pyz_bench_dense_kernel(pyz_mlp *m, int kind, int layer, const float *d_theta
   u.grad = d_grad;
   u.grad_pstride = m->D;
   for (int i = 0; i < iters; ++i) {
-    if (kind == 0) pyz_launch_fwd(g, batch, P, st);
+    if (kind == 0) {
+      if (!pyz_launch_fwd_ring(g, batch, P, st)) pyz_launch_fwd(g, batch, P, st);
+    }
     else if (kind == 1) pyz_launch_bwd_data(g, batch, P, st);
     else launch_wgrad_all(m, P, d_x, d_row_idx, batch, m->ctl, u, st, nullptr);  // the launch the step uses (all layers)
   }

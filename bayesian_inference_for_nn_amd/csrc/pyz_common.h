@@ -191,4 +191,14 @@ struct pyz_mlp {
   // what the last pyz_*_run call did: steps inside replayed graphs, eager steps, graph launches
   int run_graph_steps = 0, run_eager_steps = 0, run_graph_launches = 0;
   int *nonfinite = nullptr;                  // device counter: steps whose loss was NaN / Inf (pyz_check_finite)
+  // who wrote `grad` / `scal` last: pyz_svgd_sweep / pyz_svgd_combine consume what pyz_svgd_gradients left there and refuse
+  // anything else (pyz_hmc_step, pyz_bbb_step, ... use the same buffers)
+  int grad_owner = 0;                        // 0 nobody, 1 pyz_svgd_gradients for grad_rows particles, 2 another entry point
+  int grad_rows = 0;
+  // the snapshot whose kernel matrix (K rows of the local particles, their sums, the bandwidth) stands in the plan's
+  // float64 scratch: written by pyz_svgd_kernel_matrix, consumed by pyz_svgd_combine, dropped by every other user of the scratch
+  bool km_valid = false;
+  const float *km_all = nullptr;
+  int km_total = 0, km_row0 = 0, km_local = 0;
+  float km_gamma = 0.0f;
 };

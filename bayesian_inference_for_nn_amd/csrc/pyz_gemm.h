@@ -49,6 +49,7 @@ struct DenseArgs {
   int init_on;
   int wt;                     // forward: write-through stores for the activations (pyz_st)
   int rows_cap;               // forward, k_dense_fwd: > 0 = readable rows of a contiguous `in` (see the kernel)
+  int n_part, grid_rows;      // forward, k_dense_fwd_ring (1-D grid): particles and rows of the launch
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids

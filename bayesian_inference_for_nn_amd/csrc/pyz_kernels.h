@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(256) k_svgd_update(SvgdArgs g) {
   v = v + (phi * phi - v) * (1.0f - 0.999f);
   g.adam_m[o] = m;
   g.adam_v[o] = v;
-  const float xn = g.particles[o] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+  const float xn = xi - g.lr_t * m / (sqrtf(v) + 1e-7f);   // (x_i as the matrix holds it: `particles` is only written)
   g.particles[o] = xn;
   if (g.all_rw && g.all_rw != g.particles) g.all_rw[(long long)i * g.D + d] = xn;
 }
@@ -718,7 +718,8 @@ struct SvgdTileArgs {
   // median-heuristic bandwidth (SVGD.py:165-181) only: the squared distances of ALL pairs and the bandwidth they give
   double *dmat;            // (M, 64) squared distances (0 past M), or nullptr
   double *gamma_dev;       // [1] gamma = 1 / (2 h^2) = log(M + 1) / median(d), or nullptr: the fixed `gamma`
-  // the step's loss rides in k_svgd_kmat (its launch is 4 - 5 us for one thread's work as a kernel of its own):
+  // the step's loss rides in k_svgd_update_tile (its launch is 4 - 5 us for one thread's work as a kernel of its own; not in
+  // k_svgd_kmat: the kernel matrix of a snapshot may be built on another stream WHILE the gradient pass produces the losses):
   // loss_out[0] = sum_i loss_in[i] / M over the local particles (k_svgd_loss), or nullptr
   const float *loss_in;
   float *loss_out;
@@ -930,12 +931,6 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
 __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
   __shared__ double sl[4][64], sg[4][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
-  if (g.loss_out && !dist_only && blockIdx.x == 0 && q == 3) {   // the last wave of block 0: k_svgd_loss's arithmetic, same
-    const float mine = j < g.n_local ? g.loss_in[j] / (float)g.M : 0.0f;   // order; the loads in one round trip
-    float s = 0.0f;
-    for (int i = 0; i < g.n_local; ++i) s += __shfl(mine, i, 64);
-    if (j == 0) g.loss_out[0] = s;
-  }
   double d;
   if (g.dmat && !dist_only) {
     if (q != 0) return;
@@ -1030,6 +1025,13 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
                                                           const float *__restrict__ ksum,
                                                           const double *__restrict__ ksumd,
                                                           const double *__restrict__ gamma_dev) {
+  if (g.loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {   // the last wave of the last (ragged) block:
+    const int j = threadIdx.x & 63;                                         // k_svgd_loss's arithmetic, same order; the loads
+    const float mine = j < g.n_local ? g.loss_in[j] / (float)g.M : 0.0f;   // in one round trip
+    float s = 0.0f;
+    for (int i = 0; i < g.n_local; ++i) s += __shfl(mine, i, 64);
+    if (j == 0) g.loss_out[0] = s;
+  }
   const long long d = (long long)blockIdx.x * 256 + threadIdx.x;
   if (d >= g.D) return;
   // x_j[d] of every particle: all 64 loads are issued before the first use (rows past M repeat the last one
@@ -1066,7 +1068,9 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
     v = v + (phi * phi - v) * (1.0f - 0.999f);
     g.adam_m[o] = m;
     g.adam_v[o] = v;
-    g.particles[o] = g.particles[o] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+    // (the row's current value is the snapshot's: `particles` is only written, so a caller may alternate two buffers
+    // instead of copying the matrix for every Jacobi step)
+    g.particles[o] = xi - g.lr_t * m / (sqrtf(v) + 1e-7f);
   }
 }
 

@@ -321,6 +321,31 @@ class MLPPlan:
         check(self.lib.pyz_svgd_sweep(self.h, ptr(particles), n_local, ptr(all_particles), n_total, int(row0), ptr(adam_m),
                                       ptr(adam_v), float(lr), _gamma(gamma), int(t), SWEEP[sweep], ptr(loss_out), _stream()))
 
+    def svgd_tile_shape(self, n_local, n_total, row0) -> bool:
+        """Shapes pyz_svgd_kernel_matrix / pyz_svgd_combine take (the all-rows-at-once Jacobi kernels)."""
+        return n_total <= 64 and n_local % 4 == 0 and row0 % 4 == 0
+
+    def svgd_kernel_matrix(self, all_particles, row0, n_local, gamma, stream=None):
+        """First half of the Jacobi sweep: K rows of the local particles against the snapshot (kept inside the plan).
+        Touches neither gradients nor losses: may run on `stream` while svgd_gradients runs on another."""
+        _f32(all_particles, name="all_particles")
+        assert all_particles.dim() == 2 and all_particles.shape[1] == self.D
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+        check(self.lib.pyz_svgd_kernel_matrix(self.h, ptr(all_particles), all_particles.shape[0], int(row0), int(n_local),
+                                              _gamma(gamma), st))
+
+    def svgd_combine(self, particles, all_particles, row0, adam_m, adam_v, lr, gamma, t, loss_out):
+        """Second half: phi, Adam and the loss of every local row; after svgd_gradients AND svgd_kernel_matrix.
+        `particles` (n_local, D) is only written (the rows' current values are the snapshot's)."""
+        _f32(particles, name="particles")
+        _f32(all_particles, name="all_particles")
+        n_local, n_total = particles.shape[0], all_particles.shape[0]
+        assert particles.shape[1] == self.D and all_particles.shape[1] == self.D
+        _f32(adam_m, (n_local, self.D), "adam_m")
+        _f32(adam_v, (n_local, self.D), "adam_v")
+        check(self.lib.pyz_svgd_combine(self.h, ptr(particles), n_local, ptr(all_particles), n_total, int(row0), ptr(adam_m),
+                                        ptr(adam_v), float(lr), _gamma(gamma), int(t), ptr(loss_out), _stream()))
+
     # ------------------------------------------------------------------ R1
     def predict(self, weights, x, want_samples=True):
         _f32(weights, name="weights")

@@ -5,6 +5,8 @@ the repulsion term and the per-particle legacy Adam run on the device.
 Multi-GPU: under torch.distributed the particles are sharded by rank and every step all-gathers
 the particle matrix over RCCL (Jacobi sweep)."""
 
+import os
+
 import numpy as np
 
 from ..nn.model import model_from_json
@@ -50,11 +52,20 @@ class SVGD(Optimizer):
         from .. import parallel
         rank, world = parallel.world_info() if kwargs.get("shard", True) else (0, 1)
         self._row0, self._n_local = parallel.shard_range(self._M, world, rank)
-        self._sweep = kwargs.get("sweep", "gauss_seidel" if (world == 1 and self._gamma is not None) else "jacobi")
-        if world > 1 and self._sweep != "jacobi":
+        # _force_sharded (tests): take the sharded code path -- gather, separate local rows -- in a world of one rank
+        self._sharded = world > 1 or bool(kwargs.get("_force_sharded", False))
+        self._sweep = kwargs.get("sweep", "gauss_seidel" if (not self._sharded and self._gamma is not None) else "jacobi")
+        if self._sharded and self._sweep != "jacobi":
             raise ValueError("sharded particles need the Jacobi sweep")
         if self._gamma is None and self._sweep != "jacobi":
             raise ValueError("the median-heuristic kernel is evaluated on a snapshot: it needs the Jacobi sweep")
+        # overlap_gather: start the all-gather asynchronously on RCCL's stream and wait for it right before its first
+        # reader.  Off by default: that ordering has only run with one rank on one GPU (tests/test_gpu_multirank.py),
+        # never on a multi-GPU node (no SCALE record yet); PYZ_SVGD_OVERLAP_GATHER=1 or the kwarg opts in.
+        self._overlap_gather = bool(kwargs.get("overlap_gather", os.environ.get("PYZ_SVGD_OVERLAP_GATHER", "0") == "1"))
+        # overlap_kernel_matrix: the kernel matrix of the snapshot (a function of the particles alone, SVGD.py:183-202) on a
+        # second stream while the gradient pass runs (SVGD.py:104-111); only the combine waits for both
+        self._overlap_km = bool(kwargs.get("overlap_kernel_matrix", os.environ.get("PYZ_SVGD_OVERLAP_KM", "1") == "1"))
         # every rank draws the same batches and the same particle initialisation: one base seed for all
         self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local, chain_per_rank=False)
         self._rank, self._world = rank, world
@@ -67,13 +78,17 @@ class SVGD(Optimizer):
         fill_normal(all_p, self._seed, _lib.STREAM_INIT, 0, 0.0, 1.0)
         all_p = all_p * torch.as_tensor(rho).cuda() + torch.as_tensor(mu).cuda()
         self._all = all_p.contiguous()
-        if self._world == 1:
-            self._local = self._all                             # same storage: the sweep updates it in place
-        else:
+        self._next = None
+        if self._sharded:
             self._local = self._all[self._row0:self._row0 + self._n_local].clone()
+        else:
+            self._local = self._all                             # same storage
+            if self._sweep == "jacobi":                         # one GPU: snapshot and updated matrix alternate (no copy per step)
+                self._next = torch.empty_like(self._all)
         self._adam_m = torch.zeros((self._n_local, self._D), device="cuda")
         self._adam_v = torch.zeros((self._n_local, self._D), device="cuda")
         self._loss_dev = torch.zeros(1, device="cuda")
+        self._aux = None
         vx, vy = self._dataset.valid_data.as_numpy()
         self._val_n = len(vx)
         if self._val_n > 0:
@@ -85,35 +100,63 @@ class SVGD(Optimizer):
     def _particles_host(self):
         return self._all.cpu().numpy().astype(np.float64)
 
+    def _aux_stream(self):
+        import torch
+        if self._aux is None:
+            self._aux = torch.cuda.Stream()
+        return self._aux
+
     def step(self, save_document_path=None):
         import torch
         self._step += 1
         idx, b, _ = self._next_batch()
         from .. import parallel
-        # phase 1 -- the loss gradients -- needs the local rows only; phase 2 is the first reader of the gathered
-        # matrix.  Several ranks: the all-gather (the one exchange step of the path) runs on RCCL's stream while
-        # phase 1 computes, and the compute stream waits for it right before phase 2.
+        # phase 1 -- the loss gradients -- needs the local rows only; the kernel matrix needs the snapshot only; the
+        # combine (phi, Adam) needs both.  Several ranks: the all-gather is the one exchange step of the path.
         work = None
-        if self._world > 1:
-            work = parallel.all_gather_rows(self._local, self._all, async_op=True)
-            snapshot = self._all
+        if self._sharded:
+            work = parallel.all_gather_rows(self._local, self._all, async_op=self._overlap_gather,
+                                            force_collective=self._world == 1)
+            snapshot, target, cur = self._all, self._local, self._local
         elif self._sweep == "jacobi":
-            snapshot = self._all.clone()
+            snapshot, target, cur = self._all, self._next, self._all
         else:
-            snapshot = self._all
-        self._plan.svgd_gradients(self._local, self._x_dev, self._y_dev, batch=b, row_idx=idx)
-        if work is not None:
-            work.wait()
-        self._plan.svgd_sweep(self._local, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
-                              self._step, self._loss_dev, sweep=self._sweep)
-        # the step's loss (sum over the LOCAL particles / M) stays on the device; several ranks: the sum over
-        # ranks is taken only on the steps that record it (SVGD.py:137-139) -- a per-step all-reduce would put a
-        # second collective on the critical path for a number nobody reads
+            snapshot = target = cur = self._all
+        split = (self._sweep == "jacobi" and self._overlap_km
+                 and self._plan.svgd_tile_shape(self._n_local, self._M, self._row0))
+        if split:
+            main, aux = torch.cuda.current_stream(), self._aux_stream()
+            if work is not None:
+                with torch.cuda.stream(aux):
+                    work.wait()                                 # the aux stream waits for the gather ...
+            else:
+                aux.wait_stream(main)                           # ... or for what wrote the snapshot
+            self._plan.svgd_kernel_matrix(snapshot, self._row0, self._n_local, self._gamma, stream=aux)
+            done = aux.record_event()
+            self._plan.svgd_gradients(cur, self._x_dev, self._y_dev, batch=b, row_idx=idx)
+            main.wait_event(done)
+            if work is not None:
+                work.wait()                                     # (the combine reads the snapshot too)
+            self._plan.svgd_combine(target, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
+                                    self._step, self._loss_dev)
+        else:
+            self._plan.svgd_gradients(cur, self._x_dev, self._y_dev, batch=b, row_idx=idx)
+            if work is not None:
+                work.wait()
+            self._plan.svgd_sweep(target, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
+                                  self._step, self._loss_dev, sweep=self._sweep)
+        if self._next is not None:                              # one GPU, Jacobi: the updated matrix is the next snapshot
+            self._all, self._next = self._next, self._all
+            self._local = self._all
+        # the step's loss (sum over the LOCAL particles / M) stays on the device.  Several ranks: the sum over ranks is
+        # taken on the steps that record it (SVGD.py:137-139) and ONLY there -- a decision every rank takes alike
+        # (`verbose` is a per-process argument: a collective that depends on it pairs mismatched calls across ranks);
+        # between them the progress bar of a rank shows its own share
         record = self._step % 10 == 0                           # SVGD.py:137-139
         total_loss = self._loss_dev.clone()
-        if self._world > 1 and (record or self._verbose):       # (the progress bar shows every step's loss)
+        if self._world > 1 and record:
             parallel.sum_over_ranks(total_loss)
-        loss = DeviceScalar(total_loss, 0)                      # several ranks, quiet, unrecorded step: this rank's share
+        loss = DeviceScalar(total_loss, 0)
         if record:
             # SVGD.py:126-129 forwards the validation split through every particle on every step, but only
             # these steps keep the number: the forward runs when it is observable
@@ -134,8 +177,8 @@ class SVGD(Optimizer):
     def result(self):
         import torch
         from .. import parallel
-        if self._world > 1:
-            parallel.all_gather_rows(self._local, self._all)
+        if self._sharded:
+            parallel.all_gather_rows(self._local, self._all, force_collective=self._world == 1)
         P = self._all.cpu().numpy()
         ensemble = Ensemble()
         for i in range(self._M):                                # SVGD.py:244-249

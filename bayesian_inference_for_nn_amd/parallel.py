@@ -65,14 +65,16 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * n_local, n_local
 
 
-def all_gather_rows(local, out, async_op: bool = False):
+def all_gather_rows(local, out, async_op: bool = False, force_collective: bool = False):
     """out (world * n_local, D) <- concatenation of every rank's `local` (n_local, D).
     async_op (RCCL only): the gather runs on the communicator's own stream, ordered after the work already
     queued on the current stream; returns a handle whose wait() makes the current stream wait for it -- what
-    lies between the call and wait() overlaps with the exchange.  Otherwise returns None (complete)."""
+    lies between the call and wait() overlaps with the exchange.  Otherwise returns None (complete).
+    force_collective: issue the collective in a world of ONE rank as well (a single-GPU box then exercises the RCCL
+    call, its stream and the handle's wait -- tests/test_gpu_multirank.py); needs an initialised process group."""
     import torch.distributed as dist
     rank, world = world_info()
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         if out.data_ptr() != local.data_ptr():
             out.copy_(local)
         return None

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYZ_VERSION 200 /* 0.2.0 */
+#define PYZ_VERSION 300 /* 0.3.0 */
 
 #define PYZ_OK 0
 #define PYZ_E_INVALID (-1) /* bad argument / unsupported combination */
@@ -230,6 +230,27 @@ int pyz_svgd_gradients(pyz_mlp *mlp, const float *d_particles, int n_local, cons
 int pyz_svgd_sweep(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
                    float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, int sweep, float *d_loss,
                    void *stream);
+
+/* pyz_svgd_sweep under PYZ_SWEEP_JACOBI (at most 64 particles, row0 and n_local multiples of four) in its two halves,
+ * for callers that place work -- or a collective of their own -- between them (SVGD.py:54-68,183-202 is a function of
+ * the particle matrix alone; SVGD.py:112-123 needs the gradients too):
+ *   pyz_svgd_kernel_matrix  squared distances of rows [row0, row0 + n_local) of the snapshot d_all (M, D) against all
+ *                           of it (float64), the bandwidth when gamma == PYZ_SVGD_GAMMA_MEDIAN, K rows and their sums;
+ *                           they stay inside the plan.  It touches neither the gradients nor the losses of phase 1:
+ *                           it may run on ANOTHER stream than pyz_svgd_gradients, at the same time;
+ *   pyz_svgd_combine        phi, the legacy Adam step of every local row, d_loss -- ordered by the caller after BOTH
+ *                           (stream order or events); same d_all, rows and gamma as the kernel-matrix call.
+ * kernel_matrix + combine on one stream is what pyz_svgd_sweep runs for such shapes (bit-identical results).
+ * Under PYZ_SWEEP_JACOBI d_particles is only WRITTEN (the rows' current values are read from rows [row0, ...) of
+ * d_all): a one-GPU caller may alternate two (M, D) buffers instead of copying the matrix every step.
+ * PYZ_E_INVALID for shapes the all-rows-at-once kernels do not take (use pyz_svgd_sweep), and from pyz_svgd_combine /
+ * pyz_svgd_sweep when the plan does not hold what they consume (another entry point used its buffers in between).
+ * A plan serves one stream at a time, with this one exception. */
+int pyz_svgd_kernel_matrix(pyz_mlp *mlp, const float *d_all, int n_total, int row0, int n_local, float gamma,
+                           void *stream);
+int pyz_svgd_combine(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
+                     float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, float *d_loss,
+                     void *stream);
 
 /* ---- R1: BayesianModel.predict (BayesianModel.py:106-129): S weight draws
  * d_weights (S, D) -> d_samples (S, n, out) with NaN -> 0, d_mean (n, out). */
