@@ -262,6 +262,21 @@ class Optimizer(ABC):
         23.5 us (tools/probe_train_gap.py)."""
         stream.synchronize()
 
+    def _warn_if_diverged(self, stream=None):
+        """The device counts the steps whose loss came out NaN / Inf (survey 5.3); a quiet device-resident run prints no
+        loss, so this is where a diverged chain becomes visible: RuntimeWarning with the number of such steps.
+        Called where the host has just joined the run (one 4-byte copy)."""
+        import warnings
+        import torch
+        from .._lib import E_NAN, PyzError
+        try:
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+                self._plan.check_finite()
+        except PyzError as e:
+            if e.code != E_NAN:
+                raise
+            warnings.warn(f"{type(self).__name__}.train: {e}", RuntimeWarning, stacklevel=3)
+
     def _run_resident_chunks(self, nb_iterations: int, launch):
         """A device-resident run, planned and launched in chunks: the host lays out the batches of the next chunk
         (one permutation per epoch) while the device works through the current one.
@@ -282,6 +297,7 @@ class Optimizer(ABC):
                 launch(self._res_idx, self._res_losses, sizes, s0)
             s0 += n
         self._join_run(stream)
+        self._warn_if_diverged(stream)
         return self._res_losses[:nb_iterations]
 
     def _layer_indices(self):

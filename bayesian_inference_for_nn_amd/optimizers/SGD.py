@@ -84,6 +84,7 @@ class SGD(Optimizer):
                 raise
             return False
         self._join_run(stream)
+        self._warn_if_diverged(stream)
         # epoch bookkeeping of step() (SGD.py:45-60) for the steps just run
         last_epoch = self._plan_epoch_starts[-1] if self._plan_epoch_starts else None
         if last_epoch is None:

@@ -50,7 +50,19 @@ FLOP_PER_STEP = 654.5e6        # C2 per grad-step
 BYTES_PER_STEP = 7.03e6
 SVGD_M, SVGD_LR = 64, 0.01     # BASELINE.json configs[4]; SVGD_mnist.py:11
 SVGD_FLOP_PER_STEP = 45.2e9    # 41.9 gradients + 1.95 kernel + 1.3 repulsion
-PMC_TRAFFIC = "r02_pmc_traffic.json"
+PMC_TRAFFIC = "r03_pmc_traffic.json"
+
+
+def cpu_model() -> str:
+    """The host CPU's model string (BASELINE.md section 3 asks for it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def host_cores() -> int:
@@ -67,16 +79,21 @@ def host_cores() -> int:
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json,
-    written by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE calibrated on
-    this kernel's known byte count as MI355X_MICROARCH.md section HBM prescribes).  None if absent."""
-    for name in (PMC_TRAFFIC, "r01_pmc_traffic.json"):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (profiles/r0x_pmc_traffic.json, written
+    by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, KB units, FETCH_SIZE calibrated on this kernel's
+    known byte count as MI355X_MICROARCH.md section HBM prescribes) -- a lookup, not a counter read of THIS run (a
+    process cannot read the PMC counters of its own kernels).  Returns (bytes, detail) or (None, None):
+    bytes = counters + a modelled term (the half of a wide stream FETCH_SIZE does not see); detail names both."""
+    for name in (PMC_TRAFFIC, "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"][kernel.split("<")[0]]
-            return int(rec["hbm_bytes_per_launch"])
+            detail = {"source": "profiles/" + name + " (committed PMC passes of the same command; not read in this run)",
+                      "counter_bytes": rec.get("counter_bytes_per_launch"),
+                      "modelled_correction_bytes": rec.get("modelled_correction_bytes")}
+            return int(rec["hbm_bytes_per_launch"]), detail
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def cpu_baseline(budget_s: float = 12.0):
@@ -105,7 +122,7 @@ def cpu_baseline(budget_s: float = 12.0):
         one()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "grad-steps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{n} eager torch-CPU SGLD steps (fp32, batch {BATCH}, 784->200->10) in {dt:.1f} s; "
                       "TensorFlow is not installed, so the reference's eager step is timed through oracle/torch_eager.py"}
 
@@ -249,9 +266,10 @@ def bench_sgld(args, rank, world, backend, dev):
             k = max(kern, key=lambda n: kern[n][0])
             us_k, fl = kern[k]
             achieved = fl / (us_k * 1e-6) / 1e12
+            traffic, traffic_detail = pmc_traffic(k)
             roof = {"bound": "mfma", "kernel": k, "kernel_us": round(us_k, 3), "flop_per_launch": fl,
                     "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(k),
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
                     "kernels_us": {n: round(v[0], 3) for n, v in kern.items()},
                     "timing": "start/stop event pair per launch (hipExtLaunchKernelGGL), 256 eager steps after the timed region",
                     "whole_step": whole_step(FLOP_PER_STEP, BYTES_PER_STEP, step_us)}
@@ -284,10 +302,44 @@ def bench_sgld(args, rank, world, backend, dev):
 
 
 # ---------------------------------------------------------------------------------------------- SVGD (configs[4])
+def cpu_baseline_svgd(budget_s: float = 12.0):
+    """The reference's particle loop (SVGD.py:100-123: one tape per particle, float64 kernel row, legacy Adam) in its
+    row-wise CPU restatement (oracle/torch_eager.py + oracle/svgd.py), timed on a bounded sample of the 64 particles."""
+    import torch
+    from oracle import mlp as o_mlp, svgd as o_svgd, torch_eager
+    from bayesian_inference_for_nn_amd import synth
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    spec = o_mlp.MLPSpec(DIMS, ("relu", "softmax"), "scce")
+    M, D = SVGD_M, spec.n_params
+    x, y = synth.mnist_like(BATCH)
+    rng = np.random.default_rng(0)
+    parts = rng.normal(size=(M, D))
+    m, v = np.zeros((M, D), np.float32), np.zeros((M, D), np.float32)
+
+    def one(i, t):
+        _, g = torch_eager.flat_grad(spec, parts[i].astype(np.float32), x, y.astype(np.int64), dtype=torch.float32)
+        k_row, rep = o_svgd.rbf_row(parts, i, 1.0)
+        phi = ((k_row.sum() * np.asarray(g, np.float64) + rep) / M).astype(np.float32)
+        parts[i], m[i], v[i] = o_svgd.adam_update(parts[i].astype(np.float32), phi, m[i], v[i], t, SVGD_LR, np.float32)
+
+    one(0, 1)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s or n < 8:
+        one(n % M, 1 + n // M)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "particle-grad-steps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"{n} particle updates of the reference's Gauss-Seidel loop (eager torch-CPU fp32 tape per particle + float64 "
+                      f"kernel row over all 64 particles + legacy Adam) in {dt:.1f} s; TensorFlow is not installed"}
+
+
 def bench_svgd(args, rank, world, backend, dev):
     """64 particles of 784->200->10 sharded over the ranks, batch 1024 replicated; one all-gather of the particle
-    matrix per step (RCCL, overlapped with the gradient pass), Jacobi sweep.  Total work is fixed: strong scaling."""
+    matrix per step (RCCL), Jacobi sweep: the kernel matrix of the gathered snapshot on a second stream beside the
+    gradient pass, then the combine.  Total work is fixed: strong scaling."""
     import torch
+    import torch.distributed as dist
     from bayesian_inference_for_nn_amd import _lib, engine, parallel, synth
 
     spec = engine.MLPSpec(DIMS, ("relu", "softmax"), "scce")
@@ -297,35 +349,121 @@ def bench_svgd(args, rank, world, backend, dev):
     x_h, y_h = synth.mnist_like(N_ROWS)
     x, y = torch.as_tensor(x_h).to(dev), torch.as_tensor(y_h).to(dev)
     total = args.warmup + args.steps
-    idx_h, sizes = synth.batch_plan(N_ROWS, BATCH, total, seed=1236)            # the same batches on every rank
+    idx_h, sizes = synth.batch_plan(N_ROWS, BATCH, total + 24, seed=1236)       # the same batches on every rank
     idx = torch.as_tensor(idx_h).to(dev)
     allp = torch.empty((M, D), device=dev)
     engine.fill_normal(allp, SEED, _lib.STREAM_INIT, 0, 0.0, 1.0)               # prior N(0, 1) samples, same on every rank
     sweep = "jacobi" if (world > 1 or args.sweep == "jacobi") else "gauss_seidel"
-    local = allp if (world == 1 and sweep == "gauss_seidel") else allp[row0:row0 + n_local].clone()
+    sharded = world > 1
+    local = allp[row0:row0 + n_local].clone() if sharded else allp
+    buf = {"all": allp, "next": torch.empty_like(allp) if (not sharded and sweep == "jacobi") else None, "local": local}
     am, av = torch.zeros((n_local, D), device=dev), torch.zeros((n_local, D), device=dev)
     loss = torch.zeros(1, device=dev)
     state = {"t": 0}
+    aux = torch.cuda.Stream()
+    split = sweep == "jacobi" and plan.svgd_tile_shape(n_local, M, row0) and os.environ.get("PYZ_SVGD_OVERLAP_KM", "1") == "1"
+    overlap_gather = os.environ.get("PYZ_SVGD_OVERLAP_GATHER", "0") == "1"      # async all-gather: opt-in (never run on a node yet)
+
+    def one_step(s, ev=None):
+        """ev: optional dict of lists that receives (start, end) event pairs per phase of this step."""
+        state["t"] += 1
+        main = torch.cuda.current_stream()
+
+        def mark(stream=None):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream if stream is not None else main)
+            return e
+        t_a = mark() if ev is not None else None
+        work = None
+        if sharded:
+            work = parallel.all_gather_rows(buf["local"], buf["all"], async_op=overlap_gather)
+            snapshot, target, cur = buf["all"], buf["local"], buf["local"]
+        elif sweep == "jacobi":
+            snapshot, target, cur = buf["all"], buf["next"], buf["all"]
+        else:
+            snapshot = target = cur = buf["all"]
+        t_b = mark() if ev is not None else None          # (synchronous gather: it sits on the main stream between t_a and t_b)
+        if split:
+            if work is not None:
+                with torch.cuda.stream(aux):
+                    work.wait()
+            else:
+                aux.wait_stream(main)
+            k0 = mark(aux) if ev is not None else None
+            plan.svgd_kernel_matrix(snapshot, row0, n_local, 1.0, stream=aux)
+            done = aux.record_event()
+            k1 = mark(aux) if ev is not None else None
+            plan.svgd_gradients(cur, x, y, batch=sizes[s], row_idx=idx[s])
+            t_c = mark() if ev is not None else None
+            main.wait_event(done)
+            if work is not None:
+                work.wait()
+            plan.svgd_combine(target, snapshot, row0, am, av, SVGD_LR, 1.0, state["t"], loss)
+        else:
+            k0 = k1 = None
+            plan.svgd_gradients(cur, x, y, batch=sizes[s], row_idx=idx[s])
+            t_c = mark() if ev is not None else None
+            if work is not None:
+                work.wait()
+            plan.svgd_sweep(target, snapshot, row0, am, av, SVGD_LR, 1.0, state["t"], loss, sweep=sweep)
+        t_d = mark() if ev is not None else None
+        if buf["next"] is not None:
+            buf["all"], buf["next"] = buf["next"], buf["all"]
+        if ev is not None:
+            ev["gather"].append((t_a, t_b))
+            ev["gradients"].append((t_b, t_c))
+            ev["tail"].append((t_c, t_d))
+            ev["step"].append((t_a, t_d))
+            if k0 is not None:
+                ev["kernel_matrix"].append((k0, k1))
 
     def steps(s0, n):
         for s in range(s0, s0 + n):
-            state["t"] += 1
-            work = parallel.all_gather_rows(local, allp, async_op=True) if world > 1 else None
-            if world == 1 and sweep == "jacobi":
-                allp.copy_(local)
-            plan.svgd_gradients(local, x, y, batch=sizes[s], row_idx=idx[s])
-            if work is not None:
-                work.wait()
-            plan.svgd_sweep(local, allp, row0, am, av, SVGD_LR, 1.0, state["t"], loss, sweep=sweep)
+            one_step(s)
 
     dt = timed_region(lambda: steps(0, args.warmup), lambda: steps(args.warmup, args.steps), world, backend, dev)
     plan.check_finite()
     total_loss = loss.clone()
     parallel.sum_over_ranks(total_loss)
+    step_us = dt / args.steps * 1e6
+
+    # ---- after the timed region, independently of it: where a step's time goes on THIS rank (HIP events per phase; the
+    #      gather's share shows which all-gather algorithm RCCL picked: ~33 us direct, ~233 us ring for 5 MB per rank over
+    #      7 x ~153 GB/s xGMI links), and the kernels of one step with their own begin / end timestamps
+    ev = {k: [] for k in ("gather", "gradients", "kernel_matrix", "tail", "step")}
+    for s in range(total, total + 12):
+        one_step(s, ev)
+    torch.cuda.synchronize()
+    phases = {k: round(float(np.median([a.elapsed_time(b) * 1e3 for a, b in v])), 1) for k, v in ev.items() if v}
+    with engine.KernelProbe(512) as kp:
+        for s in range(total + 12, total + 16):
+            one_step(s)
+    per = {n: (c / 4.0, us) for n, (c, us) in kp.by_kernel().items()}
+    B, K1, N1, N2 = BATCH, DIMS[0], DIMS[1], DIMS[2]
+    f_fwd = 2.0 * B * (K1 + 1) * N1 * n_local
+    flop_of = {"k_dense_fwd": f_fwd, "k_dense_fwd_lds": f_fwd, "k_dense_fwd_ring": f_fwd,
+               "k_wgrad_all": f_fwd + 2.0 * B * (N1 + 1) * N2 * n_local,
+               "k_head_rows": (2.0 * B * (N1 + 1) * N2 + 2.0 * B * N1 * N2) * n_local}
+    kern = {n: (c, us, flop_of[n.split("<")[0]]) for n, (c, us) in per.items() if n.split("<")[0] in flop_of}
+    roof = {"bound": "mfma", "whole_step": whole_step(SVGD_FLOP_PER_STEP, 247e6, step_us),
+            "phases_us_rank0": phases,
+            "kernels_us_per_step": {n: [round(c, 2), round(us, 2)] for n, (c, us) in sorted(per.items(), key=lambda kv: -kv[1][0] * kv[1][1])}}
+    if kern:
+        k = max(kern, key=lambda n: kern[n][0] * kern[n][1])
+        c, us_k, fl = kern[k]
+        achieved = fl / (us_k * 1e-6) / 1e12
+        roof.update({"kernel": k, "kernel_us": round(us_k, 3), "flop_per_launch": fl, "achieved": round(achieved, 3),
+                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "traffic": None,
+                     "timing": "start/stop event pair per launch (hipExtLaunchKernelGGL), 4 eager steps after the timed region"})
+    all_phases = [phases]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, phases)
+        all_phases = gathered
     if rank != 0:
         return None
-    step_us = dt / args.steps * 1e6
-    return {
+    out = {
         "metric": "SVGD particle-grad-steps/sec, 64 particles, MLP 784->200->10, batch 1024",
         "value": round(M * args.steps / dt, 2),
         "unit": "particle-grad-steps/s",
@@ -336,10 +474,17 @@ def bench_svgd(args, rank, world, backend, dev):
         "config": {"workload": f"SVGD, {M} particles of MLP 784->200->10 (D=159010), batch 1024 replicated, {sweep} sweep, "
                                "gamma 1, prior N(0,1) start, eager launches",
                    "final_loss": round(float(total_loss.item()), 6),
+                   "kernel_matrix_on_second_stream": bool(split), "async_gather": bool(overlap_gather and sharded),
+                   "rccl_knobs_to_try": "NCCL_ALGO=Tree|Ring, NCCL_PROTO=Simple|LL|LL128, NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS: "
+                                        "compare phases_us_per_rank.gather across runs",
                    "parallelism": (f"particles sharded x{args.gpus} ({n_local} per GPU), one all-gather of the (64, D) matrix "
-                                   "per step overlapped with the gradient pass" if world > 1 else "1 GPU, no collective")},
-        "roofline": {"bound": "mfma", "whole_step": whole_step(SVGD_FLOP_PER_STEP, 247e6, step_us)},
+                                   "per step" if world > 1 else "1 GPU, no collective")},
+        "roofline": roof,
+        "phases_us_per_rank": all_phases,
     }
+    if not args.no_cpu_baseline and args.gpus == 1:
+        out["cpu_baseline"] = cpu_baseline_svgd()
+    return out
 
 
 def main():

@@ -230,23 +230,7 @@ def test_c4_bbb_full_shape(eng, init):
 
 
 # ------------------------------------------------------------------ C5
-def _strict_particle_check(p_gpu, st, phis, lr_ts, what):
-    """Adam's first steps move an element by ~lr_t * sign(phi) whatever |phi| is, so float32 and float64 may
-    differ by up to 2 lr_t per step on elements whose phi is (numerically) zero -- and ONLY there: elements
-    with |phi_oracle| > 1e-6 max|phi| in every step must agree to 2e-4 of the particle scale."""
-    err = np.abs(p_gpu.cpu().numpy().astype(np.float64) - st.particles)
-    strong = np.ones(err.shape, dtype=bool)
-    for phi in phis:
-        strong &= np.abs(phi) > 1e-6 * np.abs(phi).max()
-    scale = np.abs(st.particles).max()
-    assert strong.mean() > 0.5, (what, strong.mean())
-    assert err[strong].max() <= 2e-4 * scale, f"{what}: {err[strong].max():.3e} on elements with a definite phi (scale {scale:.3e})"
-    if (~strong).any():
-        assert err[~strong].max() <= 2.0 * sum(lr_ts) * 1.001 + 2e-4 * scale, f"{what}: {err[~strong].max():.3e} on phi ~ 0 elements"
-
-
-def _lr_t(lr, t):
-    return lr * np.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+from svgd_checks import lr_t as _lr_t, strict_particle_check as _strict_particle_check  # noqa: E402
 
 
 @pytest.mark.parametrize("sweep,path", [("gauss_seidel", "fused"), ("gauss_seidel", "rows"), ("jacobi", "gram"),

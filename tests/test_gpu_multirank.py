@@ -120,3 +120,44 @@ def test_two_ranks_through_the_optimizers(gpu_device):
     assert sum(a["hmc_local_freq"]) == sum(b["hmc_local_freq"]) == 6
     assert a["hmc_merged_freq"] == b["hmc_merged_freq"] == a["hmc_local_freq"] + b["hmc_local_freq"]
     assert a["hmc_merged_first"] == b["hmc_merged_first"]
+
+
+# ------------------------------------------------------------------ collectives must not depend on per-process arguments
+def _verbose_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bayesian_inference_for_nn_amd import synth
+        from bayesian_inference_for_nn_amd.datasets import Dataset
+        from bayesian_inference_for_nn_amd.distributions import GaussianPrior
+        from bayesian_inference_for_nn_amd.losses import SparseCategoricalCrossentropy
+        from bayesian_inference_for_nn_amd.nn import sequential_json
+        from bayesian_inference_for_nn_amd.optimizers import SVGD
+        from bayesian_inference_for_nn_amd.optimizers.hyperparameters import HyperParameters
+        cfg = sequential_json(2, [16, 2], ["relu", "softmax"])
+        x, y = synth.moons(500, seed=42)
+        ds = Dataset((x, y), SparseCategoricalCrossentropy, "Classification", seed=3)
+        opt = SVGD()
+        # the usual pattern: only rank 0 talks.  The sequence of collectives must be the same on both ranks anyway.
+        opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=(rank == 0), prior=GaussianPrior(0.0, 0.3), seed=9)
+        opt.train(23)                                  # crosses two recording steps (SVGD.py:137-139)
+        ens, tl, _ = opt.result()
+        ret[rank] = (np.stack([m.weights_flat for m in ens]).tolist(), [float(v) for v in tl])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_verbose_on_one_rank_only_pairs_the_same_collectives(gpu_device):
+    """SVGD.step all-reduces the loss on the steps that record it and only there: a rule every rank evaluates alike.
+    (Round 2 also reduced it whenever `verbose` printed -- a per-process argument -- so that rank 0's extra all-reduce met
+    rank 1's next all-gather.)  Two ranks, verbose on rank 0 only: the run ends, both hold the same particles and the
+    same recorded (global) losses."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_verbose_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0][0] == ret[1][0]
+    assert len(ret[0][1]) == 2 and ret[0][1] == ret[1][1]

@@ -495,15 +495,19 @@ def test_svgd_gauss_seidel_paths(eng, monkeypatch, fused):
     p = dev(parts)
     am, av = torch.zeros((M, D), device="cuda"), torch.zeros((M, D), device="cuda")
     loss = torch.zeros(1, device="cuda")
+    from svgd_checks import lr_t, strict_particle_check
+    phis, lr_ts = [], []
     for t in range(1, 3):
         plan.svgd_step(p, p, 0, am, av, dev(x), ydev(spec, y), lr, 1.0, t, loss, sweep="gauss_seidel")
         out = o_svgd.svgd_step(st, x, y, spec, lr, 1.0, sweep="gauss_seidel")
         close(loss, [out["loss"]], what="loss")
+        phis.append(out["phi"])
+        lr_ts.append(lr_t(lr, t))
     close(am, st.m, what="adam m", rel=5e-4)
     close(av, st.v, what="adam v", rel=5e-4)
-    err = np.abs(p.cpu().numpy().astype(np.float64) - st.particles)
-    assert err.max() <= 4.5 * lr, err.max()                   # at worst a sign flip in both steps
-    assert (err > 2e-4 * np.abs(st.particles).max()).mean() < 2e-3
+    # elements with a definite phi agree to 2e-4 of the particle scale; only where phi is numerically zero may Adam's
+    # lr * sign(phi) steps differ (bounded by 2 sum lr_t) -- the check of tests/test_gpu_baseline_shapes.py
+    strict_particle_check(p, st, phis, lr_ts, f"gauss_seidel fused={fused}")
     plan.close()
 
 

@@ -115,11 +115,16 @@ def main():
             am, av = torch.zeros((M, D), device=dev), torch.zeros((M, D), device=dev)
             k = [0]
 
+            bufs = [p, torch.empty_like(p)]
+
             def step():
                 s = k[0] % 16
                 k[0] += 1
-                snap = p.clone() if sweep == "jacobi" else p
-                plan.svgd_step(p, snap, 0, am, av, x, y, 0.01, 1.0, k[0], loss, sweep=sweep, batch=sizes[s], row_idx=idx[s])
+                if sweep == "jacobi":     # snapshot and updated matrix alternate (the sweep only writes its output rows)
+                    plan.svgd_step(bufs[1], bufs[0], 0, am, av, x, y, 0.01, 1.0, k[0], loss, sweep=sweep, batch=sizes[s], row_idx=idx[s])
+                    bufs.reverse()
+                else:
+                    plan.svgd_step(p, p, 0, am, av, x, y, 0.01, 1.0, k[0], loss, sweep=sweep, batch=sizes[s], row_idx=idx[s])
             us = timed(step, 20)
             with engine.KernelProbe(256) as kp:
                 step()
@@ -157,16 +162,33 @@ def main():
 
             def sweep():
                 plan.svgd_sweep(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss, sweep="jacobi")
+
+            aux = torch.cuda.Stream()
+
+            def step_overlapped():     # what SVGD.step does: kernel matrix of the snapshot on a second stream beside the gradients
+                main = torch.cuda.current_stream()
+                aux.wait_stream(main)
+                plan.svgd_kernel_matrix(allp, 0, n_local, 1.0, stream=aux)
+                done = aux.record_event()
+                grad()
+                main.wait_event(done)
+                plan.svgd_combine(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss)
+
+            def step_sequential():
+                grad()
+                sweep()
             grad()
             us_g = timed(grad, 30)
             us_s = timed(sweep, 30)
+            us_seq = timed(step_sequential, 30)
+            us_ovl = timed(step_overlapped, 30)
             with engine.KernelProbe(64) as kp:
                 grad()
                 sweep()
             print(json.dumps({"config": f"C5 SVGD one rank of {M // n_local}: {n_local} local particles of 64, B=1024 (compute only, no gather)",
-                              "gradients_us": round(us_g, 1), "sweep_us": round(us_s, 1),
+                              "gradients_us": round(us_g, 1), "sweep_us": round(us_s, 1), "step_sequential_us": round(us_seq, 1),
+                              "step_kernel_matrix_on_second_stream_us": round(us_ovl, 1),
                               "kernels_us": [(n, round(v, 1)) for n, v in kp.launches]}))
-
 
 if __name__ == "__main__":
     main()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; `bench.py --no-roofline`) into
-profiles/r02_pmc_traffic.json: HBM bytes per launch of each kernel of the SGLD step.
+profiles/r03_pmc_traffic.json: HBM bytes per launch of each kernel of the SGLD step.
 Units and corrections per MI355X_MICROARCH.md (section HBM): both counters are in KB; on gfx950
 FETCH_SIZE reports half the bytes of a WIDE (16 B/lane) coalesced stream and is uncalibrated for
 other widths, so it is calibrated here on a known byte count in our own access pattern:
@@ -31,8 +31,10 @@ def agg(pattern, counter):
     return d
 
 
-# bytes per launch read by 16-B/lane coalesced streams (counted at 1/2 by FETCH_SIZE on gfx950)
-WIDE_STREAM_BYTES = {"k_wgrad_all": 1024 * 784 * 4}
+def wide_stream_bytes(batch: int, in_width: int, batch_ahead: bool):
+    """Bytes per launch read by 16-B/lane coalesced streams (counted at 1/2 by FETCH_SIZE on gfx950): the next step's batch
+    assembled inside k_wgrad_all (batch x in_width floats) when the run assembles batches ahead (PYZ_BATCH_AHEAD != 0)."""
+    return {"k_wgrad_all": batch * in_width * 4 if batch_ahead else 0}
 
 
 def main():
@@ -43,19 +45,28 @@ def main():
     wpat = wdir if wdir.endswith(".csv") else os.path.join(wdir, "*", "*counter_collection.csv")
     f = agg(fpat, "FETCH_SIZE")
     w = agg(wpat, "WRITE_SIZE")
+    # what the profiled run really did (the driver passes them; defaults = bench.py's headline workload)
+    batch = int(os.environ.get("PYZ_PMC_BATCH", "1024"))
+    in_width = int(os.environ.get("PYZ_PMC_IN_WIDTH", "784"))
+    batch_ahead = os.environ.get("PYZ_BATCH_AHEAD", "1") != "0"
+    wide_by_kernel = wide_stream_bytes(batch, in_width, batch_ahead)
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-roofline",
-           "units": "counters in KB; hbm_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) * 1024, calibrated on the known byte count of k_wgrad_all (see tools/pmc_traffic.py); hbm_bytes_upper_bound applies the x2 FETCH_SIZE correction of 16-B/lane streams",
+           "units": "counters in KB; counter_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes_per_launch = that + modelled_correction_bytes (a MODEL term, see the field), calibrated on the known byte count of k_wgrad_all (see tools/pmc_traffic.py); hbm_bytes_upper_bound applies the x2 FETCH_SIZE correction of 16-B/lane streams",
            "kernels": {}}
     for k in ("k_dense_fwd", "k_head_rows", "k_head", "k_wgrad_all"):
         if k in f:
             fk = sum(f[k]) / len(f[k])
             wk = sum(w[k]) / len(w[k]) if k in w else 0.0
-            wide = WIDE_STREAM_BYTES.get(k, 0)
+            wide = wide_by_kernel.get(k, 0)
             out["kernels"][k] = {"launches": len(f[k]), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
-                                 "wide_stream_bytes_counted_at_half": wide,
+                                 # the counters alone, and the MODELLED term added to them (not a measurement: the half of a
+                                 # wide stream the counter does not see, from this run's batch x input width)
+                                 "counter_bytes_per_launch": int((fk + wk) * 1024),
+                                 "modelled_correction_bytes": wide // 2,
+                                 "modelled_from": {"batch": batch, "in_width": in_width, "batch_ahead": batch_ahead},
                                  "hbm_bytes_per_launch": int((fk + wk) * 1024 + wide // 2),
                                  "hbm_bytes_upper_bound": int((2 * fk + wk) * 1024)}
-    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

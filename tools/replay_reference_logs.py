@@ -130,6 +130,51 @@ def oracle_bbb_classification(lr, alpha, batch, hidden, seed, steps=600):
     return {"accuracy": 100.0 * float((probs.argmax(1) == ye).mean())}
 
 
+def oracle_svgd_classification(lr, batch, M, seed, steps=1000):
+    from oracle import mlp as o_mlp, svgd as o_svgd
+    rng = np.random.default_rng(seed)
+    (xt, yt), (xe, ye) = split(*make_moons(2000, 0.2, rng), rng)          # SVGD_classification.py:130,145-149
+    spec = o_mlp.MLPSpec((2, 64, 2), ("relu", "softmax"), "scce")         # :152-155
+    st = o_svgd.SVGDState(rng.normal(size=(M, spec.n_params)), wdtype=np.float32)    # prior N(0, 1): :158
+    s = 0
+    while s < steps:
+        perm = rng.permutation(len(xt))
+        for o in range(0, len(xt), batch):
+            if s == steps:
+                break
+            rows = perm[o:o + batch]
+            o_svgd.svgd_step(st, xt[rows], yt[rows], spec, lr, 1.0)
+            s += 1
+    probs = np.mean([o_mlp.predict(p, xe, spec) for p in st.particles], axis=0)      # :86-93 ensemble mean of the softmax outputs
+    return {"accuracy": float((probs.argmax(1) == ye).mean())}
+
+
+def oracle_bbb_regression(lr, alpha, batch, hidden, seed, steps=2000):
+    from oracle import bbb as o_bbb, mlp as o_mlp
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(1, 20, size=(600, 1)).astype(np.float32)              # BBB_regression.py:37-38
+    y = (2 * x + 2).astype(np.float32)
+    (xt, yt), (xe, ye) = split(x, y, rng)
+    spec = o_mlp.MLPSpec((1, hidden, 1), ("linear", "linear"), "mse")     # :48-51
+    D = spec.n_params
+    pm, pr = o_bbb.mix_prior(0.0, 1.0)                                    # :54; BBB.py:258-270
+    mu, rho = np.full(D, pm), np.full(D, pr)
+    s = 0
+    while s < steps:
+        perm = rng.permutation(len(xt))
+        for o in range(0, len(xt), batch):
+            if s == steps:
+                break
+            rows = perm[o:o + batch]
+            out = o_bbb.bbb_step(mu, rho, rng.normal(size=D), xt[rows], yt[rows], spec, lr, alpha, pm, pr)
+            mu, rho = out["mu"], out["rho"]
+            s += 1
+    loc, scale = o_bbb.result_distribution(mu, rho)
+    pred = np.mean([o_mlp.predict(loc + scale * rng.normal(size=D), xe, spec) for _ in range(10)], axis=0)   # :73 n_boundaries=10
+    pred = np.nan_to_num(pred)
+    return {"mse": float(((pred - ye.reshape(pred.shape)) ** 2).mean())}
+
+
 # ------------------------------------------------------------------------------------------------ gpu backend
 def _surface():
     from bayesian_inference_for_nn_amd.datasets import Dataset
@@ -192,8 +237,58 @@ def gpu_bbb_classification(lr, alpha, batch, hidden, seed, steps=600):
     return {"accuracy": 100.0 * float((np.asarray(mean).argmax(1) == ye.reshape(-1)).mean())}
 
 
+def gpu_svgd_classification(lr, batch, M, seed, steps=1000):
+    s = _surface()
+    rng = np.random.default_rng(seed)
+    ds = s["Dataset"](make_moons(2000, 0.2, rng), s["SparseCategoricalCrossentropy"], "Classification", seed=seed)
+    opt = s["SVGD"]()
+    opt.compile(s["HyperParameters"](lr=lr, batch_size=batch, M=M), s["sequential_json"](2, [64, 2], ["relu", "softmax"]), ds,
+                verbose=False, prior=s["GaussianPrior"](0, 1), seed=seed)
+    opt.train(steps)
+    models, _, _ = opt.result()
+    xe, ye = _test_split(ds)
+    probs = np.mean([np.asarray(mm.predict(xe)) for mm in models], axis=0)
+    return {"accuracy": float((probs.argmax(1) == ye.reshape(-1)).mean())}
+
+
+def gpu_bbb_regression(lr, alpha, batch, hidden, seed, steps=2000):
+    s = _surface()
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(1, 20, size=(600, 1)).astype(np.float32)
+    ds = s["Dataset"]((x, (2 * x + 2).astype(np.float32)), s["MeanSquaredError"], "Regression", seed=seed)
+    opt = s["BBB"]()
+    opt.compile(s["HyperParameters"](lr=lr, alpha=alpha, batch_size=batch), s["sequential_json"](1, [hidden, 1], ["linear", "linear"]),
+                ds, verbose=False, prior=s["GaussianPrior"](0.0, 1.0), seed=seed)
+    opt.train(steps)
+    bm, _, _ = opt.result()
+    xe, ye = _test_split(ds)
+    _, mean = bm.predict(xe, nb_samples=10)
+    mean = np.asarray(mean)
+    return {"mse": float(((mean - ye.reshape(mean.shape)) ** 2).mean())}
+
+
 BACKENDS = {"oracle": (oracle_hmc, oracle_svgd_regression, oracle_bbb_classification),
             "gpu": (gpu_hmc, gpu_svgd_regression, gpu_bbb_classification)}
+EXTRA = {"oracle": (oracle_svgd_classification, oracle_bbb_regression),
+         "gpu": (gpu_svgd_classification, gpu_bbb_regression)}
+
+
+def replay_extra(backend: str, what=("svgd_cls", "bbb_reg"), seeds=2, svgd_rows=None, bbb_rows=None):
+    """The two logs added in round 3 (SVGD_classification_FULL.txt, BBB_regression_FULL.txt): one run per seed and row."""
+    f_svgd, f_bbb = EXTRA[backend]
+    g = golden()
+    out = {}
+    if "svgd_cls" in what:
+        out["svgd_cls"] = []
+        for row in (svgd_rows if svgd_rows is not None else g["svgd_classification"]["rows"]):
+            runs = [f_svgd(row["lr"], row["batch_size"], row["M"], seed)["accuracy"] for seed in range(seeds)]
+            out["svgd_cls"].append(dict(row, runs=runs, mean=float(np.mean(runs))))
+    if "bbb_reg" in what:
+        out["bbb_reg"] = []
+        for row in (bbb_rows if bbb_rows is not None else g["bbb_regression"]["rows"]):
+            runs = [f_bbb(row["lr"], row["alpha"], row["batch_size"], row["hidden_dims"], seed)["mse"] for seed in range(seeds)]
+            out["bbb_reg"].append(dict(row, runs=runs, median=float(np.median(runs))))
+    return out
 
 
 def replay(backend: str, what=("hmc", "svgd", "bbb"), seeds=3, hmc_rows=None, svgd_rows=None, bbb_rows=None):
