@@ -1524,7 +1524,12 @@ int pyz_svgd_combine(pyz_mlp *m, float *d_particles, int n_local, const float *d
 int pyz_svgd_step(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
                   float *d_adam_m, float *d_adam_v, const float *d_x, const void *d_y, const int32_t *d_row_idx,
                   int batch, float lr, float gamma, int64_t t, int sweep, float *d_loss, void *stream) {
-  const int rc = svgd_gradients_impl(m, d_particles, n_local, d_x, d_y, d_row_idx, batch, as_stream(stream));
+  // Under the Jacobi sweep d_particles is only written (pyz.h): the rows' current values -- what the gradients are taken
+  // at -- are rows [row0, row0 + n_local) of the snapshot
+  if (!d_all || !d_particles) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n_total < n_local || row0 < 0 || row0 + n_local > n_total) return pyz_fail(PYZ_E_INVALID, "rows [%d, %d) outside the %d particles", row0, row0 + n_local, n_total);
+  const float *cur = (sweep == PYZ_SWEEP_JACOBI && d_all != d_particles && m) ? d_all + (long long)row0 * m->D : d_particles;
+  const int rc = svgd_gradients_impl(m, cur, n_local, d_x, d_y, d_row_idx, batch, as_stream(stream));
   if (rc) return rc;
   return svgd_sweep_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, sweep, d_loss,
                          as_stream(stream));

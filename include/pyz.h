@@ -242,7 +242,8 @@ int pyz_svgd_sweep(pyz_mlp *mlp, float *d_particles, int n_local, const float *d
  *                           (stream order or events); same d_all, rows and gamma as the kernel-matrix call.
  * kernel_matrix + combine on one stream is what pyz_svgd_sweep runs for such shapes (bit-identical results).
  * Under PYZ_SWEEP_JACOBI d_particles is only WRITTEN (the rows' current values are read from rows [row0, ...) of
- * d_all): a one-GPU caller may alternate two (M, D) buffers instead of copying the matrix every step.
+ * d_all -- by pyz_svgd_step's gradient pass too): a one-GPU caller may alternate two (M, D) buffers instead of copying
+ * the matrix every step.  (pyz_svgd_gradients takes the current rows explicitly.)
  * PYZ_E_INVALID for shapes the all-rows-at-once kernels do not take (use pyz_svgd_sweep), and from pyz_svgd_combine /
  * pyz_svgd_sweep when the plan does not hold what they consume (another entry point used its buffers in between).
  * A plan serves one stream at a time, with this one exception. */
