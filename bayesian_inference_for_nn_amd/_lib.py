@@ -49,6 +49,8 @@ SIGNATURES = {
     "pyz_probe_begin": (C.c_int, [C.c_int]),
     "pyz_probe_end": (C.c_int, [_p, C.POINTER(_f), C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "pyz_bbb_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, _f, _f, _f, _f, _p, _p, _i64, _u64, _p, _p, _p]),
+    "pyz_bbb_run": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.POINTER(_i32), C.POINTER(_f), C.c_int, _f, _f, _f, _p, _p, _i64,
+                              _i64, _u64, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p]),
     "pyz_hmc_step": (C.c_int, [_p, _p, C.c_int, _p, _p, C.c_int, C.c_int, _f, _f, _f, _f, _p, _p, C.c_int, C.POINTER(_f),
                                _i64, _u64, _p, _p, _p]),
     "pyz_svgd_step": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _p, _p, _p, C.c_int, _f, _f, _i64,

@@ -162,11 +162,13 @@ DenseArgs forward_args(pyz_mlp *m, int l, const float *theta, long long theta_ps
 // forward over layers [0, l_end); activations land in m->act[l]
 void launch_forward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x,
                     const int32_t *row_idx, int grid_batch, const StepCtl *ctl, hipStream_t st,
-                    float *gather_out = nullptr, int l_end = -1) {
+                    float *gather_out = nullptr, int l_end = -1, const StepCtl *gate = nullptr, int gate_mod = 0) {
   if (l_end < 0) l_end = m->L;
   for (int l = 0; l < l_end; ++l) {
     DenseArgs g = forward_args(m, l, theta, theta_ps, x, row_idx, ctl, gather_out);
     g.wt = pyz_wt_for(P);
+    g.gate = gate;
+    g.gate_mod = gate_mod;
     if (pyz_launch_fwd_ring(g, grid_batch, P, st)) continue;   // mid-size launches: 32-row blocks through the LDS-DMA ring
     if (!g.row_idx && !g.init_on && !g.gather_out) g.rows_cap = std::min(grid_batch, m->max_batch);   // (layer 0 of a caller-owned x: its rows cover grid_batch by contract)
     pyz_launch_fwd(g, grid_batch, P, st);
@@ -247,9 +249,12 @@ void launch_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, 
 inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
 
 void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
-                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st) {
+                 const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st,
+                 const StepCtl *gate = nullptr, int gate_mod = 0) {
   const int l = m->L - 1;
   HeadArgs g{};
+  g.gate = gate;
+  g.gate_mod = gate_mod;
   g.K = m->dims[l];
   g.N = m->dims[l + 1];
   if (l == 0) {
@@ -677,11 +682,70 @@ struct SwagChain {  // chained SWAG run: the (k, D) deviation matrix and the two
   int k, freq;
 };
 
+struct BbbChain {  // chained BBB run: what the step needs beside mu (= theta), and the optional validation forward
+  float *rho, *w;
+  float alpha, prior_mean, prior_rho;
+  const float *pm_vec, *pr_vec;
+  pyz_mlp *val;             // plan of the validation forward (max_batch >= n_val), or nullptr
+  const float *val_x;
+  const void *val_y;
+  int n_val;
+  float *val_losses;        // [slot] per step; written on the steps that validate (BBB.py:203: step % 10 != 0)
+};
+
 static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
                              uint64_t seed, const float *unit_noise, float *loss, hipStream_t st, int mode = PYZ_UPD_SGLD,
-                             const SwagChain *swag = nullptr) {
+                             const SwagChain *swag = nullptr, const BbbChain *bbb = nullptr) {
   const StepCtl *ctl = m->ctl + slot;
+  if (bbb) {   // BBB.step (BBB.py:128-211) inside a device-resident run: scalars from StepCtl, cost into slot (slot0 + i)
+    const int nblk_kl = cdiv(cdiv(m->D, 4), 256);
+    BbbArgs a{};
+    a.mu = theta;
+    a.rho = bbb->rho;
+    a.w = bbb->w;
+    a.D = m->D;
+    a.alpha = bbb->alpha;
+    a.prior_mean = bbb->prior_mean;
+    a.prior_rho = bbb->prior_rho;
+    a.pm_vec = bbb->pm_vec;
+    a.pr_vec = bbb->pr_vec;
+    a.seed = seed;
+    a.part_kl = full(m)->x.part2;
+    a.nblk_kl = nblk_kl;
+    a.ctl = ctl;
+    a.chained = 1;
+    PYZ_LAUNCH(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
+    WgradArgs u{};
+    u.mode = PYZ_UPD_BBB;
+    u.theta = theta;
+    u.mean = bbb->rho;
+    u.sq_mean = bbb->w;
+    u.seed = seed;
+    u.alpha = bbb->alpha;
+    u.prior_mean = bbb->prior_mean;
+    u.prior_rho = bbb->prior_rho;
+    u.pm_vec = bbb->pm_vec;
+    u.pr_vec = bbb->pr_vec;
+    u.bbb_chained = 1;
+    u.part_kl = full(m)->x.part2;
+    u.nblk_kl = nblk_kl;
+    u.cost = loss;
+    u.next = chained ? m->ctl + (slot ^ 1) : nullptr;
+    u.tab_bs = m->tab_bs;
+    u.tab_lr = m->tab_lr;
+    u.row_stride = row_stride;
+    const bool ahead = chained && batch_ahead(m, row_idx);
+    if (ahead) u.prep = prep_args(m, x, row_idx, grid_batch, row_stride, slot ^ 1);
+    launch_loss_backward(m, bbb->w, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st, ahead ? slot : -1);
+    if (bbb->val) {   // the validation split through the weights this step sampled; the launches do nothing on every tenth step
+      pyz_mlp *v = bbb->val;
+      launch_forward(v, bbb->w, v->D, 1, bbb->val_x, nullptr, bbb->n_val, v->ctl, st, nullptr, v->L - 1, ctl, 10);
+      launch_head(v, bbb->w, v->D, 1, bbb->val_x, bbb->val_y, nullptr, bbb->n_val, v->ctl, false, st, ctl, 10);
+      PYZ_LAUNCH(k_loss_finalize_gated, dim3(1), dim3(64), 0, st, v->part, v->cur_nblk, v->ctl, bbb->val_losses, v->nonfinite, ctl, 10);
+    }
+    return;
+  }
   if (can_fuse(m)) {
     WgradArgs u{};
     u.mode = mode;  // PYZ_UPD_SGLD, or PYZ_UPD_SGD / PYZ_UPD_SWAG for the chained SGD / SWAG runs (fused path only)
@@ -752,7 +816,7 @@ int pyz_sgld_step(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, c
 static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_mean, const float *d_x, const void *d_y,
                          const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
                          int64_t n0, int64_t slot0, uint64_t seed, float *d_losses, int use_graph, void *stream,
-                         int mode = PYZ_UPD_SGLD, const SwagChain *swag = nullptr) {
+                         int mode = PYZ_UPD_SGLD, const SwagChain *swag = nullptr, const BbbChain *bbb = nullptr) {
   if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
   if (mode != PYZ_UPD_SGLD && !can_fuse(m))
     return pyz_fail(PYZ_E_INVALID, "the chained SGD / SWAG runs need a last layer of at most 32 units");
@@ -772,6 +836,15 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   pyz_mlp_full *f = full(m);
   hipStream_t st = as_stream(stream);
+  if (bbb) {
+    if ((rc = need_part2(m, cdiv(cdiv(m->D, 4), 256)))) return rc;
+    if (bbb->val) {   // the validation plan's step scalars: its batch is the whole split, for every step of the run
+      pyz_mlp *v = bbb->val;
+      if (v->D != m->D || !can_fuse(v) || bbb->n_val < 1 || bbb->n_val > v->max_batch || !bbb->val_x || !bbb->val_y || !bbb->val_losses)
+        return pyz_fail(PYZ_E_INVALID, "validation plan / split does not fit the model");
+      if ((rc = set_ctl(v, 0, bbb->n_val, 0.0f, 0, 0, 0, st))) return rc;
+    }
+  }
   // per-run tables (one padding entry: the last step prepares a slot nobody reads); batch sizes and learning
   // rates share one device allocation
   const size_t n_tab = (size_t)n_steps + 1;
@@ -859,6 +932,14 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
     // (not the stream: an instantiated graph launches on any stream, and a caller that takes a fresh stream per run --
     // torch hands them out of a pool -- would otherwise re-capture every graph on every call)
     if (swag) { mix((unsigned long long)(uintptr_t)swag->dev); mix((unsigned long long)swag->k); mix((unsigned long long)swag->freq); }
+    if (bbb) {
+      unsigned fb[3];
+      memcpy(&fb[0], &bbb->alpha, 4); memcpy(&fb[1], &bbb->prior_mean, 4); memcpy(&fb[2], &bbb->prior_rho, 4);
+      for (unsigned b : fb) mix(b);
+      mix((unsigned long long)(uintptr_t)bbb->pm_vec); mix((unsigned long long)(uintptr_t)bbb->pr_vec);
+      mix((unsigned long long)(uintptr_t)bbb->val); mix((unsigned long long)(uintptr_t)bbb->val_x); mix((unsigned long long)(uintptr_t)bbb->val_y);
+      mix((unsigned long long)bbb->n_val); mix((unsigned long long)(uintptr_t)bbb->val_losses);
+    }
     if (m->graph_key != key) {
       drop_graphs(m);
       m->graph_key = key;
@@ -889,7 +970,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
         PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         for (int k = 0; k < len; ++k)
           launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
-                           nullptr, d_losses, st, mode, swag);
+                           nullptr, d_losses, st, mode, swag, bbb);
         hipGraph_t gr = nullptr;
         PYZ_HIP(hipStreamEndCapture(st, &gr));
         m->graph[ci] = gr;
@@ -905,7 +986,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   }
   for (; s < n_steps; ++s) {
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
-                     d_losses, st, mode, swag);
+                     d_losses, st, mode, swag, bbb);
     ++m->run_eager_steps;
   }
   PYZ_LAUNCH_CHECK();
@@ -1005,6 +1086,35 @@ int pyz_bbb_step(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float 
   }
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
+}
+
+// The BBB train loop (BBB.py:128-211 inside Optimizer.py:121-134) as one device-resident run: per step the launch
+// sequence of pyz_bbb_step with the step scalars on the device (learning rate from the table, Philox step = step0 + i),
+// batches assembled one step ahead, the cost triple of step i in d_costs[4 (slot0 + i) ..], and -- with a validation
+// plan -- the validation split forwarded through the weights the step sampled on the steps BBB.py:203 validates
+// (step % 10 != 0; the launches are in every step of the graph and return at once on the others).
+int pyz_bbb_run(pyz_mlp *m, float *d_mu, float *d_rho, float *d_w, const float *d_x, const void *d_y,
+                const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps, float alpha,
+                float prior_mean, float prior_rho, const float *d_prior_mean_vec, const float *d_prior_rho_vec, int64_t step0,
+                int64_t slot0, uint64_t seed, float *d_costs, pyz_mlp *val_plan, const float *d_val_x, const void *d_val_y,
+                int n_val, float *d_val_losses, int use_graph, void *stream) {
+  if (!d_rho || !d_w) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (step0 < 0) return pyz_fail(PYZ_E_INVALID, "negative step count");
+  BbbChain bc{};
+  bc.rho = d_rho;
+  bc.w = d_w;
+  bc.alpha = alpha;
+  bc.prior_mean = prior_mean;
+  bc.prior_rho = prior_rho;
+  bc.pm_vec = d_prior_mean_vec;
+  bc.pr_vec = d_prior_rho_vec;
+  bc.val = val_plan;
+  bc.val_x = d_val_x;
+  bc.val_y = d_val_y;
+  bc.n_val = n_val;
+  bc.val_losses = d_val_losses;
+  return sgld_run_impl(m, d_mu, d_rho, d_w, d_x, d_y, d_row_idx, h_batch_sizes, h_lr, n_steps, step0, slot0, seed, d_costs,
+                       use_graph, stream, PYZ_UPD_BBB, nullptr, &bc);
 }
 
 // ---------------------------------------------------------------- H2-H5

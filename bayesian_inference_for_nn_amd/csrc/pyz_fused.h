@@ -42,6 +42,8 @@ struct HeadArgs {
   StepCtl init;              // the step scalars by value when the head is the first kernel of an eager step (L == 1)
   int init_on;
   int wt;                    // write-through stores for the outputs (pyz_st)
+  const StepCtl *gate;       // when set: nothing happens on steps with gate->n % gate_mod == 0 (see DenseArgs)
+  int gate_mod;
 };
 
 // lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
@@ -61,6 +63,7 @@ __global__ void __launch_bounds__(512) k_head(HeadArgs g) {
   extern __shared__ float lds[];
   PYZ_STAMP(1, 0);
   const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+  if (g.gate && g.gate->n % g.gate_mod == 0) return;
   float *red = lds, *zt = lds + S * 1024, *dt = zt + 32 * 33;
   double *lsum = reinterpret_cast<double *>(dt + 32 * 33);  // 4 doubles (8-byte aligned: S*4096 + 8448 bytes)
   const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
@@ -431,6 +434,7 @@ template <int UT, int NP, int RW = 1>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
   const int w = pyz_wave_id(), l = threadIdx.x & 63;
+  if (g.gate && g.gate->n % g.gate_mod == 0) return;
   const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
   const int batch = ctl.batch, p = blockIdx.y;
   const int m0 = (blockIdx.x * 4 + w) * RW;  // this wave's first batch row (scalar)
@@ -605,6 +609,7 @@ struct WgradArgs {
   float alpha, prior_mean, prior_rho, bbb_lr;
   const float *pm_vec, *pr_vec;
   uint32_t bbb_step;
+  int bbb_chained;            // device-resident run: learning rate and step count come from StepCtl, cost goes to slot (slot0 + i)
   const double *part_kl;
   int nblk_kl;
   float *cost;
@@ -667,8 +672,9 @@ __device__ __forceinline__ PyzUpdOut pyz_update_math(const WgradArgs &g, const i
     const float g_mu = g.alpha * d * is2;
     const float g_rho = g.alpha * (-1.0f / sg + d * d * is2 / sg) * sig;
     const float g_w = gv + g.alpha * (-d * is2 + (wv - pmean) * isp2);
-    o.th = mu - g.bbb_lr * (g_mu + g_w);
-    o.mu = rho - g.bbb_lr * (zz * sig * g_w + g_rho);
+    const float blr = g.bbb_chained ? lr : g.bbb_lr;
+    o.th = mu - blr * (g_mu + g_w);
+    o.mu = rho - blr * (zz * sig * g_w + g_rho);
     o.wr_mu = true;
   } else if (mode == PYZ_UPD_SGLD) {
     const float fn = (float)nstep, fn1 = fn + 1.0f;
@@ -711,10 +717,12 @@ __device__ __forceinline__ void pyz_step_duties(const WgradArgs &g, const int l)
     const double v = pyz_sum_partials(g.part, g.nblk), k = pyz_sum_partials(g.part_kl, g.nblk_kl);
     if (l == 0) {
       const float loss = (float)(v / (double)batch), kl = (float)k;
-      g.cost[0] = loss + g.alpha * kl;
-      pyz_note_loss(g.nonfinite, g.cost[0]);
-      g.cost[1] = loss;
-      g.cost[2] = kl;
+      float *co = g.cost + (g.bbb_chained ? 4 * (g.ctl->slot0 + g.ctl->i) : 0);
+      co[0] = loss + g.alpha * kl;
+      pyz_note_loss(g.nonfinite, co[0]);
+      co[1] = loss;
+      co[2] = kl;
+      if (g.bbb_chained && g.next) pyz_prepare_next(g.ctl, g.next, g.tab_bs, g.tab_lr, g.row_stride);
     }
   }
 }
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
 #pragma unroll
       for (int q = 0; q < EPT; ++q) {
         zg[q] = mode == PYZ_UPD_SGLD ? pyz_normal1(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)ee[q])
-                                     : pyz_normal1(g.seed, PYZ_STREAM_BBB, g.bbb_step, (uint64_t)ee[q]);
+                                     : pyz_normal1(g.seed, PYZ_STREAM_BBB, g.bbb_chained ? (uint32_t)nstep : g.bbb_step, (uint64_t)ee[q]);
       }
     }
   };

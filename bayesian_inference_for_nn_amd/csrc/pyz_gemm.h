@@ -50,6 +50,8 @@ struct DenseArgs {
   int wt;                     // forward: write-through stores for the activations (pyz_st)
   int rows_cap;               // forward, k_dense_fwd: > 0 = readable rows of a contiguous `in` (see the kernel)
   int n_part, grid_rows;      // forward, k_dense_fwd_ring (1-D grid): particles and rows of the launch
+  const StepCtl *gate;        // forward (k_dense_fwd): when set, the launch does nothing on steps with gate->n % gate_mod == 0
+  int gate_mod;               // (the validation forward of a device-resident BBB run: BBB.py:203 skips every tenth step)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so ids
@@ -313,6 +315,7 @@ __global__ void k_dense_fwd(DenseArgs g) {
   const int S = blockDim.x >> 6, w = pyz_wave_id(), l = threadIdx.x & 63;
   const int r = l & 31, h = l >> 5;
   const int tiles_n = (g.N + 31) >> 5;
+  if (g.gate && g.gate->n % g.gate_mod == 0) return;   // (uniform)
   const int tile = pyz_xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   // rows_cap > 0 (contiguous input with that many readable rows, e.g. the batch assembled ahead): the operand loads
@@ -689,7 +692,7 @@ static inline bool pyz_fwd_takes_lds(const DenseArgs &g, int grid_batch, int P, 
   const long long wg128 = (long long)((grid_batch + 127) / 128) * ((g.N + 32 * NT - 1) / (32 * NT)) * P;
   // (row counts past lds_max_rows: only launches of many particles -- predict with all its draws in one launch: 3.3 ms
   // against 4.9 for 100 draws x 10 000 rows; with two draws per launch the one-wave kernel won, 14.5 against 16.7 ms)
-  return S == 1 && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && (grid_batch <= lds_max_rows || P >= 8) &&
+  return S == 1 && !g.gate && lds_on && lds_ok && g.N >= 48 && grid_batch >= 128 && (grid_batch <= lds_max_rows || P >= 8) &&
          wg128 >= pyz_env_int("PYZ_FWD_LDS_MINWG", 256);
 }
 

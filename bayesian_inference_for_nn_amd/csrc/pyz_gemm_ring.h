@@ -379,7 +379,7 @@ static inline int pyz_fwd_ring_variant(const DenseArgs &g, int grid_batch, int P
   static const int on = pyz_env_int("PYZ_FWD_RING", 1);
   static const int min_wg = pyz_env_int("PYZ_FWD_RING_MINWG", 192);
   static const int max_wg = pyz_env_int("PYZ_FWD_RING_MAXWG", 1024);
-  if (!on) return 0;
+  if (!on || g.gate) return 0;
   const long long wgs = (long long)((grid_batch + 31) / 32) * P;
   if (wgs < min_wg || wgs > max_wg) return 0;
   if (g.K % 4 || g.N % 4 || g.lda % 4 || g.w_off % 4 || (P > 1 && g.in_pstride % 4)) return 0;

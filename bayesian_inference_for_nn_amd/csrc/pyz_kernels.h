@@ -180,6 +180,18 @@ __global__ void k_loss_mse(LossArgs g) {
 }
 
 // loss[p] = (sum of the row-loss partials) / batch
+// gate (optional): the launch does nothing on steps with gate->n % gate_mod == 0, and writes to loss[gate->slot0 + gate->i]
+__global__ void k_loss_finalize_gated(const double *part, int nblk, const StepCtl *ctl, float *loss, int *nonfinite,
+                                      const StepCtl *gate, int gate_mod) {
+  if (gate->n % gate_mod == 0) return;
+  const double tot = pyz_sum_partials(part, nblk);
+  if (threadIdx.x == 0) {
+    float *lo = loss + gate->slot0 + gate->i;
+    lo[0] = (float)(tot / (double)ctl->batch);
+    pyz_note_loss(nonfinite, lo[0]);
+  }
+}
+
 __global__ void k_loss_finalize(const double *part, int nblk, const StepCtl *ctl, float *loss, int *nonfinite) {
   const int p = blockIdx.x;   // one 64-lane wave per particle
   const double tot = pyz_sum_partials(part + p * nblk, nblk);
@@ -307,6 +319,7 @@ struct BbbArgs {
   int nblk_loss;
   const StepCtl *ctl;
   float *cost;           // [0] = cost, [1] = data loss, [2] = log q - log p
+  int chained;           // device-resident run: the Philox step is ctl->n
 };
 
 __device__ __forceinline__ void pyz_bbb_eps(const BbbArgs &g, long long t, float *z) {
@@ -315,7 +328,7 @@ __device__ __forceinline__ void pyz_bbb_eps(const BbbArgs &g, long long t, float
 #pragma unroll
     for (int j = 0; j < 4; ++j) z[j] = (e0 + j < g.D) ? g.eps[e0 + j] : 0.0f;
   } else {
-    const float4 q = pyz_normal4(g.seed, PYZ_STREAM_BBB, g.step, (uint64_t)t);
+    const float4 q = pyz_normal4(g.seed, PYZ_STREAM_BBB, g.chained ? (uint32_t)g.ctl->n : g.step, (uint64_t)t);
     z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
   }
 }

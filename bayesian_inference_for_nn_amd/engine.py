@@ -263,6 +263,41 @@ class MLPPlan:
                                     float(alpha), float(prior_mean), float(prior_rho), ptr(prior_mean_vec),
                                     ptr(prior_rho_vec), int(step), int(seed), ptr(eps), ptr(cost_out), _stream()))
 
+    def bbb_run(self, mu, rho, w, x, y, row_idx, batch_sizes, lrs, alpha, prior_mean, prior_rho, step0, seed, costs_out,
+                use_graph=True, slot0=0, prior_mean_vec=None, prior_rho_vec=None, val_plan=None, val_x=None, val_y=None,
+                val_losses_out=None):
+        """n = len(batch_sizes) BBB steps without host work in between (see sgld_run for the table layout); costs_out
+        (slots, 4): {cost, data loss, log q - log p, -} per step.  val_plan / val_x / val_y / val_losses_out (slots):
+        the validation forward of BBB.py:203-209 inside the run (steps with step % 10 != 0)."""
+        n_steps = len(batch_sizes)
+        assert len(lrs) == n_steps and n_steps > 0
+        for t, nm in ((mu, "mu"), (rho, "rho"), (w, "w")):
+            _f32(t, (self.D,), nm)
+        for t, nm in ((prior_mean_vec, "prior_mean_vec"), (prior_rho_vec, "prior_rho_vec")):
+            if t is not None:
+                _f32(t, (self.D,), nm)
+        self._check_xy(x, y, row_idx, 1)
+        _f32(costs_out, name="costs_out")
+        if slot0 < 0 or row_idx.numel() < (slot0 + n_steps) * self.max_batch or costs_out.numel() < 4 * (slot0 + n_steps):
+            raise ValueError("row_idx / costs_out too small")
+        if any(int(b) < 1 or int(b) > self.max_batch for b in batch_sizes):
+            raise ValueError("batch size outside the plan")
+        n_val = 0
+        if val_plan is not None:
+            _f32(val_x, name="val_x")
+            n_val = int(val_x.shape[0])
+            if val_x.shape[1] != self.spec.dims[0] or n_val > val_plan.max_batch or val_plan.D != self.D:
+                raise ValueError("validation split does not fit the validation plan")
+            _f32(val_losses_out, name="val_losses_out")
+            if val_losses_out.numel() < slot0 + n_steps:
+                raise ValueError("val_losses_out too small")
+        bs = (C.c_int32 * n_steps)(*[int(b) for b in batch_sizes])
+        lr = (C.c_float * n_steps)(*[float(v) for v in lrs])
+        check(self.lib.pyz_bbb_run(self.h, ptr(mu), ptr(rho), ptr(w), ptr(x), ptr(y), ptr(row_idx), bs, lr, n_steps, float(alpha),
+                                   float(prior_mean), float(prior_rho), ptr(prior_mean_vec), ptr(prior_rho_vec), int(step0),
+                                   int(slot0), int(seed), ptr(costs_out), val_plan.h if val_plan is not None else None,
+                                   ptr(val_x), ptr(val_y), n_val, ptr(val_losses_out), 1 if use_graph else 0, _stream()))
+
     # ------------------------------------------------------------------ H2-H5
     def hmc_step(self, q, x, y, L, epsilon, m, prior_mean, prior_sigma, uniforms, step, seed, stats_out, burning=False,
                  unit_p=None, prior_mean_vec=None, prior_sigma_vec=None):

@@ -91,6 +91,44 @@ class BBB(Optimizer):
             self.train_losses.append(likelihood)
         return likelihood
 
+    def _train_resident(self, nb_iterations: int) -> bool:
+        """verbose=False: all steps in device-resident runs (pyz_bbb_run: hipGraph replay, batches assembled one step
+        ahead, the validation forward of BBB.py:203-209 inside the run).  Equal to the per-step loop bit for bit."""
+        import torch
+        from .._lib import PyzError
+        if nb_iterations <= 0:
+            return True
+        if self._spec.dims[-1] > 32:                            # the chained step needs the fused head
+            return False
+        self._reserve_resident(nb_iterations)
+        if getattr(self, "_res_costs", None) is None or self._res_costs.shape[0] < self._res_cap:
+            self._res_costs = torch.zeros((self._res_cap, 4), device="cuda")
+            self._res_val = torch.zeros(self._res_cap, device="cuda")
+        lr, step0 = float(self._lr), self._step + 1
+        has_val = self._val_n > 0
+
+        def launch(idx, _losses, sizes, s0):
+            self._plan.bbb_run(self._mu, self._rho, self._w, self._x_dev, self._y_dev, idx, sizes, [lr] * len(sizes),
+                               self._alpha, self._pm, self._pr, step0 + s0, self._seed, self._res_costs, use_graph=True,
+                               slot0=s0, prior_mean_vec=self._pm_vec, prior_rho_vec=self._pr_vec,
+                               val_plan=self._val_plan if has_val else None, val_x=self._vx if has_val else None,
+                               val_y=self._vy if has_val else None, val_losses_out=self._res_val if has_val else None)
+        try:
+            self._run_resident_chunks(nb_iterations, launch)
+        except PyzError:
+            if self._step + 1 != step0:
+                raise
+            return False
+        costs, vals = self._res_costs[:nb_iterations].clone(), self._res_val[:nb_iterations].clone()
+        for i in range(nb_iterations):
+            if (step0 + i) % 10:                                # BBB.py:203: nine steps out of ten, as written
+                if has_val:
+                    self.val_losses.append(DeviceScalar(vals, i))
+                self.train_losses.append(DeviceScalar(costs, 4 * i))
+        self._cost[:4].copy_(costs[-1])
+        self._step += nb_iterations
+        return True
+
     def update_parameters_step(self):
         pass
 

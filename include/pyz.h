@@ -184,6 +184,20 @@ int pyz_bbb_step(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const floa
                  const float *d_prior_rho_vec, int64_t step, uint64_t seed,
                  const float *d_eps, float *d_cost, void *stream);
 
+/* The BBB train loop (BBB.step inside Optimizer.train, Optimizer.py:121-134) as ONE device-resident run of n_steps
+ * steps, replayed from captured hipGraphs like pyz_sgld_run: d_row_idx (slots, max_batch) / h_batch_sizes / h_lr as
+ * there; step i of the call is optimizer step step0 + i (its Philox step) and writes {cost, data loss, log q - log p}
+ * to d_costs[4 (slot0 + i) ..].  Needs a last layer of at most 32 units.  val_plan (optional; a second plan of the same
+ * model with max_batch >= n_val): on the steps BBB.py:203 validates (step % 10 != 0) the validation split d_val_x /
+ * d_val_y is forwarded through the weights the step sampled and its mean loss goes to d_val_losses[slot0 + i].
+ * Results equal n_steps calls of pyz_bbb_step (+ pyz_mlp_loss_grad on the validation plan) bit for bit. */
+int pyz_bbb_run(pyz_mlp *mlp, float *d_mu, float *d_rho, float *d_w, const float *d_x, const void *d_y,
+                const int32_t *d_row_idx, const int32_t *h_batch_sizes, const float *h_lr, int n_steps,
+                float alpha, float prior_mean, float prior_rho, const float *d_prior_mean_vec,
+                const float *d_prior_rho_vec, int64_t step0, int64_t slot0, uint64_t seed, float *d_costs,
+                pyz_mlp *val_plan, const float *d_val_x, const void *d_val_y, int n_val,
+                float *d_val_losses, int use_graph, void *stream);
+
 /* ---- H2-H5: one HMC proposal (HMC.py:74-104) for P independent chains on the
  * full training split (d_x, d_y, n_rows).  d_q (P, D) is updated in place when
  * accepted.  Momentum p = m * z with z from Philox (seed, step, chain) or

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def doc_blocks():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     blocks = re.findall(r"```python\n# \[integration:(\w+)\]\n(.*?)```", text, flags=re.S)
-    assert [b[0] for b in blocks] == ["load", "plan", "sgld", "hmc"], [b[0] for b in blocks]
+    assert [b[0] for b in blocks] == ["load", "plan", "sgld", "hmc", "svgd"], [b[0] for b in blocks]
     return blocks
 
 
@@ -33,7 +33,8 @@ def run_doc(names):
 def test_documented_argtypes_match_the_header():
     from bayesian_inference_for_nn_amd import _lib
     ns = run_doc(["load"])
-    assert set(ns["ARGTYPES"]) >= {"pyz_mlp_create", "pyz_sgld_step", "pyz_hmc_step", "pyz_malloc", "pyz_upload", "pyz_download"}
+    assert set(ns["ARGTYPES"]) >= {"pyz_mlp_create", "pyz_sgld_step", "pyz_hmc_step", "pyz_malloc", "pyz_upload", "pyz_download",
+                                   "pyz_svgd_gradients", "pyz_svgd_kernel_matrix", "pyz_svgd_combine", "pyz_bbb_run"}
     for name, args in ns["ARGTYPES"].items():
         res, ref = _lib.SIGNATURES[name]
         assert res is C.c_int, name
@@ -104,3 +105,47 @@ def test_route_b_sgld_step_and_hmc_proposal_match_the_oracle(gpu_device):
     for d in (d_q, d_x, d_y, d_stats):
         check(pyz.pyz_free(d))
     check(pyz.pyz_mlp_destroy(h))
+
+
+@pytest.mark.gpu
+def test_route_b_sharded_svgd_step_with_a_caller_side_exchange(gpu_device):
+    """[integration:svgd] as written: two shards of 4 particles driven one after the other from NumPy buffers; the
+    "all-gather" between the calls is the caller's (here: device-to-host, concatenate, host-to-device).  Against the
+    oracle's Jacobi step (SVGD.py:54-68,100-129)."""
+    from oracle import mlp as o_mlp, svgd as o_svgd
+    ns = run_doc(["load", "plan", "sgld", "hmc", "svgd"])
+    pyz, check, to_device, to_host = ns["pyz"], ns["check"], ns["to_device"], ns["to_host"]
+    spec = o_mlp.MLPSpec((24, 16, 4), ("relu", "softmax"), "scce")
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=(90, 24)).astype(np.float32)
+    y = rng.integers(0, 4, size=90).astype(np.int32)
+    rows = rng.permutation(90)[:40].astype(np.int32)
+    M, D, nl = 8, spec.n_params, 4
+    parts = (rng.normal(size=(M, D)) * 0.05).astype(np.float32)
+    d_x, d_y, d_rows = to_device(x), to_device(y), to_device(rows)
+    host_matrix = parts.copy()
+    shards = []
+    for r in range(2):
+        h = ns["make_plan"](spec.dims, (1, 4), 0, 40, nl)
+        shards.append(dict(h=h, row0=nl * r, local=to_device(parts[nl * r:nl * r + nl]), gathered=to_device(parts),
+                           m=to_device(np.zeros((nl, D), np.float32)), v=to_device(np.zeros((nl, D), np.float32)),
+                           loss=to_device(np.zeros(1, np.float32))))
+
+    def exchange(d_local, d_gathered):          # every shard's rows are in host_matrix (read back after its last step)
+        check(pyz.pyz_upload(d_gathered, host_matrix.ctypes.data_as(C.c_void_p), host_matrix.nbytes, None))
+
+    st = o_svgd.SVGDState(parts)
+    for t in (1, 2):
+        for sh in shards:
+            ns["svgd_sharded_step"](sh["h"], sh["local"], nl, sh["row0"], sh["gathered"], M, sh["m"], sh["v"], d_x, d_y, d_rows, 40,
+                                    0.01, t, sh["loss"], exchange)
+        for sh in shards:                       # the caller's gather for the next step
+            host_matrix[sh["row0"]:sh["row0"] + nl] = to_host(sh["local"], (nl, D))
+        out = o_svgd.svgd_step(st, x[rows], y[rows], spec, 0.01, 1.0, sweep="jacobi")
+        total = sum(float(to_host(sh["loss"], (1,))[0]) for sh in shards)
+        assert abs(total - out["loss"]) <= 1e-4 * abs(out["loss"])
+    got_m = np.concatenate([to_host(sh["m"], (nl, D)) for sh in shards])
+    assert np.abs(got_m - st.m).max() <= 2e-4 * np.abs(st.m).max()
+    assert np.abs(host_matrix - st.particles).max() <= 2.0 * 2 * 0.01 * 3.2 + 1e-6      # Adam's first steps: lr_t ~ 3.2 lr at t = 1
+    for sh in shards:
+        check(pyz.pyz_mlp_destroy(sh["h"]))
