@@ -344,6 +344,12 @@ void launch_bwd_data_hidden(pyz_mlp *m, const float *theta, long long theta_ps, 
   }
 }
 
+inline int wgrad_tiles(const pyz_mlp *m) {   // workgroups of k_wgrad_all that own a 32 x 32 tile (launch_wgrad_all's count)
+  int tiles = 0;
+  for (int l = 0; l < m->L; ++l) tiles += ((m->dims[l] + 1 + 31) / 32) * ((m->dims[l + 1] + 31) / 32);
+  return tiles;
+}
+
 // every layer's weight gradient in one launch; `a` carries the update mode and its buffers
 void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx, int grid_batch, const StepCtl *ctl,
                       WgradArgs &a, hipStream_t st, const float *gathered) {
@@ -684,6 +690,7 @@ struct SwagChain {  // chained SWAG run: the (k, D) deviation matrix and the two
 
 struct BbbChain {  // chained BBB run: what the step needs beside mu (= theta), and the optional validation forward
   float *rho, *w;
+  float *w2;                // sampling fused into the weight-gradient epilogue: the second weight buffer (steps on StepCtl slot 1), or nullptr
   float alpha, prior_mean, prior_rho;
   const float *pm_vec, *pr_vec;
   pyz_mlp *val;             // plan of the validation forward (max_batch >= n_val), or nullptr
@@ -696,31 +703,42 @@ struct BbbChain {  // chained BBB run: what the step needs beside mu (= theta), 
 static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, const float *x, const void *y,
                              const int32_t *row_idx, int grid_batch, int slot, bool chained, long long row_stride,
                              uint64_t seed, const float *unit_noise, float *loss, hipStream_t st, int mode = PYZ_UPD_SGLD,
-                             const SwagChain *swag = nullptr, const BbbChain *bbb = nullptr) {
+                             const SwagChain *swag = nullptr, const BbbChain *bbb = nullptr, bool first = true) {
   const StepCtl *ctl = m->ctl + slot;
   if (bbb) {   // BBB.step (BBB.py:128-211) inside a device-resident run: scalars from StepCtl, cost into slot (slot0 + i)
-    const int nblk_kl = cdiv(cdiv(m->D, 4), 256);
-    BbbArgs a{};
-    a.mu = theta;
-    a.rho = bbb->rho;
-    a.w = bbb->w;
-    a.D = m->D;
-    a.alpha = bbb->alpha;
-    a.prior_mean = bbb->prior_mean;
-    a.prior_rho = bbb->prior_rho;
-    a.pm_vec = bbb->pm_vec;
-    a.pr_vec = bbb->pr_vec;
-    a.seed = seed;
-    a.part_kl = full(m)->x.part2;
-    a.nblk_kl = nblk_kl;
-    a.ctl = ctl;
-    a.chained = 1;
-    PYZ_LAUNCH(k_bbb_sample, dim3(nblk_kl), dim3(256), 0, st, a);
+    // Sampling fused (bbb->w2): the weights and the log q - log p partials of step i + 1 come out of step i's weight-gradient
+    // epilogue, into the buffers of the other StepCtl slot; only the first step of a chunk launches k_bbb_sample (for a later
+    // chunk it rewrites what the chunk before left: same Philox step, same mu / rho).
+    const int nblk_sample = cdiv(cdiv(m->D, 4), 256), tiles = wgrad_tiles(m);
+    const bool fuse = bbb->w2 != nullptr;
+    const size_t kl_stride = (size_t)std::max(nblk_sample, tiles);
+    double *kl_cur = full(m)->x.part2 + (fuse ? (size_t)slot * kl_stride : 0);
+    double *kl_next = full(m)->x.part2 + (size_t)(slot ^ 1) * kl_stride;
+    float *w_cur = (fuse && slot) ? bbb->w2 : bbb->w, *w_next = slot ? bbb->w : bbb->w2;
+    const bool sample = !fuse || first;
+    if (sample) {
+      BbbArgs a{};
+      a.mu = theta;
+      a.rho = bbb->rho;
+      a.w = w_cur;
+      a.D = m->D;
+      a.alpha = bbb->alpha;
+      a.prior_mean = bbb->prior_mean;
+      a.prior_rho = bbb->prior_rho;
+      a.pm_vec = bbb->pm_vec;
+      a.pr_vec = bbb->pr_vec;
+      a.seed = seed;
+      a.part_kl = kl_cur;
+      a.nblk_kl = nblk_sample;
+      a.ctl = ctl;
+      a.chained = 1;
+      PYZ_LAUNCH(k_bbb_sample, dim3(nblk_sample), dim3(256), 0, st, a);
+    }
     WgradArgs u{};
     u.mode = PYZ_UPD_BBB;
     u.theta = theta;
     u.mean = bbb->rho;
-    u.sq_mean = bbb->w;
+    u.sq_mean = w_cur;
     u.seed = seed;
     u.alpha = bbb->alpha;
     u.prior_mean = bbb->prior_mean;
@@ -728,8 +746,12 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
     u.pm_vec = bbb->pm_vec;
     u.pr_vec = bbb->pr_vec;
     u.bbb_chained = 1;
-    u.part_kl = full(m)->x.part2;
-    u.nblk_kl = nblk_kl;
+    u.part_kl = kl_cur;
+    u.nblk_kl = sample ? nblk_sample : tiles;
+    if (fuse) {
+      u.w_next = w_next;
+      u.part_kl_next = kl_next;
+    }
     u.cost = loss;
     u.next = chained ? m->ctl + (slot ^ 1) : nullptr;
     u.tab_bs = m->tab_bs;
@@ -737,11 +759,11 @@ static void launch_sgld_step(pyz_mlp *m, float *theta, float *mean, float *sq, c
     u.row_stride = row_stride;
     const bool ahead = chained && batch_ahead(m, row_idx);
     if (ahead) u.prep = prep_args(m, x, row_idx, grid_batch, row_stride, slot ^ 1);
-    launch_loss_backward(m, bbb->w, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st, ahead ? slot : -1);
+    launch_loss_backward(m, w_cur, m->D, 1, x, y, row_idx, grid_batch, ctl, true, u, st, ahead ? slot : -1);
     if (bbb->val) {   // the validation split through the weights this step sampled; the launches do nothing on every tenth step
       pyz_mlp *v = bbb->val;
-      launch_forward(v, bbb->w, v->D, 1, bbb->val_x, nullptr, bbb->n_val, v->ctl, st, nullptr, v->L - 1, ctl, 10);
-      launch_head(v, bbb->w, v->D, 1, bbb->val_x, bbb->val_y, nullptr, bbb->n_val, v->ctl, false, st, ctl, 10);
+      launch_forward(v, w_cur, v->D, 1, bbb->val_x, nullptr, bbb->n_val, v->ctl, st, nullptr, v->L - 1, ctl, 10);
+      launch_head(v, w_cur, v->D, 1, bbb->val_x, bbb->val_y, nullptr, bbb->n_val, v->ctl, false, st, ctl, 10);
       PYZ_LAUNCH(k_loss_finalize_gated, dim3(1), dim3(64), 0, st, v->part, v->cur_nblk, v->ctl, bbb->val_losses, v->nonfinite, ctl, 10);
     }
     return;
@@ -836,8 +858,16 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   if (!can_fuse(m) && (rc = need_grad(m, 1))) return rc;
   pyz_mlp_full *f = full(m);
   hipStream_t st = as_stream(stream);
+  BbbChain bbb_local{};
   if (bbb) {
-    if ((rc = need_part2(m, cdiv(cdiv(m->D, 4), 256)))) return rc;
+    static const int fuse_sample = pyz_env_int("PYZ_BBB_FUSE_SAMPLE", 1);
+    if ((rc = need_part2(m, 2 * (size_t)std::max(cdiv(cdiv(m->D, 4), 256), wgrad_tiles(m))))) return rc;
+    if (fuse_sample) {   // the plan's gradient buffer (idle on the fused path) is the second weight buffer
+      if ((rc = need_grad(m, 1))) return rc;
+      bbb_local = *bbb;
+      bbb_local.w2 = m->grad;
+      bbb = &bbb_local;
+    }
     if (bbb->val) {   // the validation plan's step scalars: its batch is the whole split, for every step of the run
       pyz_mlp *v = bbb->val;
       if (v->D != m->D || !can_fuse(v) || bbb->n_val < 1 || bbb->n_val > v->max_batch || !bbb->val_x || !bbb->val_y || !bbb->val_losses)
@@ -939,6 +969,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
       mix((unsigned long long)(uintptr_t)bbb->pm_vec); mix((unsigned long long)(uintptr_t)bbb->pr_vec);
       mix((unsigned long long)(uintptr_t)bbb->val); mix((unsigned long long)(uintptr_t)bbb->val_x); mix((unsigned long long)(uintptr_t)bbb->val_y);
       mix((unsigned long long)bbb->n_val); mix((unsigned long long)(uintptr_t)bbb->val_losses);
+      mix((unsigned long long)(uintptr_t)bbb->w2); mix((unsigned long long)(uintptr_t)bbb->rho); mix((unsigned long long)(uintptr_t)full(m)->x.part2);
     }
     if (m->graph_key != key) {
       drop_graphs(m);
@@ -970,7 +1001,7 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
         PYZ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         for (int k = 0; k < len; ++k)
           launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, k & 1, true, row_stride, seed,
-                           nullptr, d_losses, st, mode, swag, bbb);
+                           nullptr, d_losses, st, mode, swag, bbb, k == 0);
         hipGraph_t gr = nullptr;
         PYZ_HIP(hipStreamEndCapture(st, &gr));
         m->graph[ci] = gr;
@@ -986,9 +1017,12 @@ static int sgld_run_impl(pyz_mlp *m, float *d_theta, float *d_mean, float *d_sq_
   }
   for (; s < n_steps; ++s) {
     launch_sgld_step(m, d_theta, d_mean, d_sq_mean, d_x, d_y, d_row_idx, bmax, s & 1, true, row_stride, seed, nullptr,
-                     d_losses, st, mode, swag, bbb);
+                     d_losses, st, mode, swag, bbb, s == 0);
     ++m->run_eager_steps;
   }
+  // fused sampling: the weights of the last step stand in the second buffer when it ran on StepCtl slot 1
+  if (bbb && bbb->w2 && ((n_steps - 1) & 1))
+    PYZ_HIP(hipMemcpyAsync(bbb->w, bbb->w2, sizeof(float) * (size_t)m->D, hipMemcpyDeviceToDevice, st));
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }

@@ -613,6 +613,11 @@ struct WgradArgs {
   const double *part_kl;
   int nblk_kl;
   float *cost;
+  // chained BBB runs, sampling fused: the epilogue also draws the NEXT step's weights from the mu / rho it just wrote
+  // (w_next, Philox step n + 1 -- k_bbb_sample's arithmetic) and leaves that step's log q - log p partial of its tile in
+  // part_kl_next[workgroup]; nullptr = the step's own k_bbb_sample launch does both
+  float *w_next;
+  double *part_kl_next;
   // duties of workgroup 0 at the end of the step: loss and the next step's scalars
   const double *part;
   int nblk;
@@ -815,6 +820,8 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
   bool ev[EPT];
   float th0[PLAIN ? 1 : EPT], mu0[PLAIN ? 1 : EPT], sq0[PLAIN ? 1 : EPT], zz[PLAIN ? 1 : EPT];
   float zg[PLAIN ? 1 : EPT];   // generated noise: its own registers (writing a register a load may still be filling waits for EVERY load in flight)
+  float zn[PLAIN ? 1 : EPT];   // BBB with fused sampling: the next step's eps
+  const bool fuse_next = !PLAIN && mode == PYZ_UPD_BBB && g.w_next != nullptr;
   auto prefetch = [&]() {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -845,6 +852,10 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
         zg[q] = mode == PYZ_UPD_SGLD ? pyz_normal1(g.seed, PYZ_STREAM_SGLD, (uint32_t)nstep, (uint64_t)ee[q])
                                      : pyz_normal1(g.seed, PYZ_STREAM_BBB, g.bbb_chained ? (uint32_t)nstep : g.bbb_step, (uint64_t)ee[q]);
       }
+    }
+    if (!PLAIN && fuse_next) {
+#pragma unroll
+      for (int q = 0; q < EPT; ++q) zn[q] = pyz_normal1(g.seed, PYZ_STREAM_BBB, (uint32_t)(nstep + 1), (uint64_t)ee[q]);
     }
   };
 
@@ -905,6 +916,12 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
     }
   }
   PYZ_STAMP(2, 4);
+  double klp = 0.0;
+  float sp_s = 1.0f, lsp_s = 0.0f;
+  if (!PLAIN && fuse_next) {
+    sp_s = pyz_softplus(g.prior_rho);
+    lsp_s = logf(sp_s);
+  }
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
     if (!ev[q]) continue;
@@ -912,8 +929,38 @@ __global__ void __launch_bounds__(64 * S) k_wgrad_all(WgradArgs g) {
       pyz_st(g.grad + p * g.grad_pstride + ee[q], gv[q], g.wt);
       continue;
     }
-    pyz_update_store(g, mode, ee[q], p, gv[q], pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q],
-                                                               PLAIN ? 0.0f : (g.unit_noise ? zz[q] : zg[q]), lr, nstep));
+    const PyzUpdOut o = pyz_update_math(g, mode, ee[q], gv[q], th0[q], mu0[q], sq0[q],
+                                        PLAIN ? 0.0f : (g.unit_noise ? zz[q] : zg[q]), lr, nstep);
+    pyz_update_store(g, mode, ee[q], p, gv[q], o);
+    if (fuse_next) {   // k_bbb_sample's element, from the mu (o.th) and rho (o.mu) of this update
+      const long long e = ee[q];
+      const float pmean = g.pm_vec ? g.pm_vec[e] : g.prior_mean;
+      float sp = sp_s, lsp = lsp_s;
+      if (g.pr_vec) {
+        sp = pyz_softplus(g.pr_vec[e]);
+        lsp = logf(sp);
+      }
+      const float mu = o.th, sg = pyz_softplus(o.mu);
+      const float wn = zn[q] * sg + mu;
+      pyz_st(g.w_next + e, wn, g.wt);
+      const float a = (wn - mu) / sg, b = (wn - pmean) / sp;
+      const float lq = -0.5f * a * a - logf(sg) - PYZ_LOG_SQRT_2PI;
+      const float lp = -0.5f * b * b - lsp - PYZ_LOG_SQRT_2PI;
+      klp += (double)lq - (double)lp;
+    }
+  }
+  if (!PLAIN && fuse_next) {   // (uniform over the launch) this tile's share of the next step's log q - log p
+    double tot = pyz_wave_sum(klp);
+    if (S > 1) {
+      double *sm = reinterpret_cast<double *>(red);
+      __syncthreads();   // every wave is done reading the tile partials in `red`
+      if (l == 0) sm[w] = tot;
+      __syncthreads();
+      tot = 0.0;
+      if (threadIdx.x == 0)
+        for (int ww = 0; ww < S; ++ww) tot += sm[ww];
+    }
+    if (threadIdx.x == 0) g.part_kl_next[blockIdx.x] = tot;
   }
   PYZ_STAMP(2, 3);
 }
