@@ -34,6 +34,8 @@ struct Extra {  // lazily sized buffers kept beside the plan
   size_t grad_cap = 0, grad2_cap = 0, qsave_cap = 0, part_cap = 0, part2_cap = 0, scal_cap = 0;
   void *hm_buf = nullptr;  // k_hmc_multi: state / slab ping-pong buffers
   size_t hm_cap = 0;
+  void *hm_res_buf = nullptr;  // k_hmc_resident: per-chain epochs and the granule rows
+  size_t hm_res_cap = 0;
   hipGraph_t hm_graph = nullptr;  // the launch sequence of one sliced HMC proposal
   hipGraphExec_t hm_exec = nullptr;
   unsigned long long hm_key = 0;
@@ -564,7 +566,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->nonfinite};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->x.hm_res_buf, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) {
@@ -1266,18 +1268,56 @@ int pyz_hmc_step(pyz_mlp *m, float *d_q, int P, const float *d_x, const void *d_
         if (mlds > 64 * 1024)
           PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kmulti), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         mm.call = call_dev;
-        // one graph per (kernel, shapes, pointers, scalars): a proposal is L + 2 dependent launches
+        // the whole proposal as one resident launch (k_hmc_resident) when its NW x chains workgroups fit the chip at once
+        void (*kres)(HmcMultiArgs) = nullptr;
+#define PYZ_HR_PICK(ACT)                                                                         \
+  kres = bucket == 0 ? k_hmc_resident<2, 2, ACT> : (bucket == 1 ? k_hmc_resident<4, 4, ACT> : k_hmc_resident<8, 8, ACT>)
+        switch (m->acts[0]) {
+          case PYZ_ACT_RELU: PYZ_HR_PICK(PYZ_ACT_RELU); break;
+          case PYZ_ACT_TANH: PYZ_HR_PICK(PYZ_ACT_TANH); break;
+          case PYZ_ACT_SIGMOID: PYZ_HR_PICK(PYZ_ACT_SIGMOID); break;
+          default: PYZ_HR_PICK(PYZ_ACT_LINEAR); break;
+        }
+#undef PYZ_HR_PICK
+        bool resident = pyz_env_int("PYZ_HMC_RESIDENT", 1) != 0 && NW * P <= pyz_cu_count();   // (read per call: tests flip it)
+        if (resident) {
+          if (mlds > 64 * 1024)
+            PYZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+          int per_cu = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kres), PYZ_HM_THREADS, mlds) != hipSuccess || per_cu < 1)
+            resident = false;
+        }
+        if (resident) {
+          const int Dp = (int)((D + 2 + 31) / 32 * 32);
+          const size_t rbytes = 256 + sizeof(unsigned long long) * 2 * (size_t)P * NW * Dp;
+          const size_t had = fm->x.hm_res_cap;
+          if ((rc = ensure_bytes(&fm->x.hm_res_buf, &fm->x.hm_res_cap, rbytes, m))) return rc;
+          if (fm->x.hm_res_cap != had)   // a fresh buffer: epochs and tags start at zero (the kernel's tags are >= 1 and only grow)
+            PYZ_HIP(hipMemsetAsync(fm->x.hm_res_buf, 0, fm->x.hm_res_cap, st));
+          mm.epoch = reinterpret_cast<unsigned *>(fm->x.hm_res_buf);
+          mm.gran = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(fm->x.hm_res_buf) + 256);
+          mm.Dp = Dp;
+          mm.spin_limit = pyz_env_int("PYZ_HMC_SPIN_LIMIT", 1 << 20);
+#ifdef PYZ_HMC_DIAG
+          mm.diag = pyz_env_int("PYZ_HMC_DIAG", 0);
+#endif
+        }
+        // one graph per (kernel, shapes, pointers, scalars): a proposal is L + 2 dependent launches (resident: a memset and one launch)
         unsigned long long key = 1469598103934665603ull;
         auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
-        mix((unsigned long long)(uintptr_t)kmulti); mix((unsigned long long)L); mix((unsigned long long)P); mix((unsigned long long)NW);
+        mix((unsigned long long)(uintptr_t)(resident ? kres : kmulti)); mix((unsigned long long)(uintptr_t)mm.gran); mix((unsigned long long)mm.spin_limit + 7 * (unsigned long long)mm.diag); mix((unsigned long long)L); mix((unsigned long long)P); mix((unsigned long long)NW);
         mix((unsigned long long)n_rows); mix((unsigned long long)(uintptr_t)d_q); mix((unsigned long long)(uintptr_t)d_x);
         mix((unsigned long long)(uintptr_t)d_y); mix((unsigned long long)(uintptr_t)d_unit_p); mix((unsigned long long)(uintptr_t)d_stats);
         mix((unsigned long long)(uintptr_t)fm->x.hm_buf); mix((unsigned long long)(uintptr_t)st);
         unsigned fbits[4];
         memcpy(&fbits[0], &epsilon, 4); memcpy(&fbits[1], &mass, 4); memcpy(&fbits[2], &prior_mean, 4); memcpy(&fbits[3], &prior_sigma, 4);
         for (unsigned b : fbits) mix(b);
-        static const int use_graph = pyz_env_int("PYZ_HMC_GRAPH", 1);
+        const int use_graph = pyz_env_int("PYZ_HMC_GRAPH", 1);   // (read per call: tests flip it)
         auto launch_all = [&]() {
+          if (resident) {
+            PYZ_LAUNCH(kres, dim3(NW, P), dim3(PYZ_HM_THREADS), mlds, st, mm);
+            return;
+          }
           for (int t = 0; t <= L; ++t) {
             mm.t = t;
             PYZ_LAUNCH(kmulti, dim3(NW, P), dim3(PYZ_HM_THREADS), mlds, st, mm);

@@ -50,8 +50,20 @@ __device__ unsigned long long pyz_dbg_buf[PYZ_STAMP_KERNELS][PYZ_STAMP_BLOCKS][P
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   } while (0)
+// lap counters kept in registers (`lap`: unsigned long long[16], [15] = the last reading): cycles since the previous lap are
+// added to lap[slot]; every wave runs it (scalar), the kernel decides which wave writes its counters out
+#define PYZ_LAP(lap, slot)                                                                   \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    (lap)[slot] += t_ - (lap)[15];                                                           \
+    (lap)[15] = t_;                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
 #else
 #define PYZ_STAMP(kid, slot)
+#define PYZ_LAP(lap, slot)
 #endif
 
 // wave index inside the workgroup as a SCALAR: threadIdx.x >> 6 is wave-uniform, but the compiler

@@ -123,7 +123,8 @@ __device__ __forceinline__ double pyz_hf_row_tail(const HmcFusedArgs &a, const f
 // wj[j] = { W1[0..MI)[j], W2[j][0..MC), b1[j], 0 } is rebuilt from q at every call.
 template <int MI, int MC, int ACT, int WAVES = PYZ_HF_WAVES>
 __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *g, float *part, float *wj,
-                                   const float *xs, float *d2, const float *yf, double *sm, const int nloc) {
+                                   const float *xs, float *d2, const float *yf, double *sm, const int nloc,
+                                   unsigned long long *lap = nullptr) {
   constexpr int SJ = MI + MC + 2;
   constexpr int THREADS = 64 * WAVES;
   const int N = nloc, I = a.I, H = a.H, C = a.C;
@@ -138,8 +139,42 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     wj[e] = v;
   }
   __syncthreads();
-  // ---------------- phase A: rows (two per pass: every weight record read feeds two rows)
+  if (lap) PYZ_LAP(lap, 0);
+  // ---------------- phase A
   double lsum = 0.0;
+  if constexpr (WAVES <= 4) {
+    // row slices (a few dozen rows on 256 threads): TWO lanes per row, each takes half of the hidden units, and the two
+    // partial logits are added across the lane pair (a + b on one lane, b + a on the other: the same bits).  One lane per
+    // row leaves most of the workgroup idle behind a loop over all H units (k_hmc_resident: 4 600 of 19 000 cycles
+    // per gradient evaluation).
+    const int half = t & 1, H0 = (H + 1) >> 1;
+    const int jb = half ? H0 : 0, je = half ? H : H0;
+    for (int rbase = 0; rbase < N; rbase += THREADS / 2) {
+      const int r = rbase + (t >> 1);
+      const bool has = r < N;
+      const int rc = has ? r : N - 1;   // (spare lanes redo the last row: same values to the same places)
+      float x0[MI], z0[MC];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) x0[i] = xs[rc * MI + i];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) z0[c] = (half == 0 && c < C) ? b2[c] : 0.0f;
+#pragma unroll 5
+      for (int j = jb; j < je; ++j) {
+        const float *rec = wj + j * SJ;
+        float h0 = rec[MI + MC];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) h0 = fmaf(x0[i], rec[i], h0);
+        h0 = pyz_act(h0, ACT);
+#pragma unroll
+        for (int c = 0; c < MC; ++c) z0[c] = fmaf(h0, rec[MI + c], z0[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < MC; ++c) z0[c] = z0[c] + __shfl_xor(z0[c], 1, 64);
+      const double tail = pyz_hf_row_tail<MC>(a, z0, d2 + rc * MC, yf, rc);
+      if (has && half == 0) lsum += tail;
+    }
+  } else {
+  // rows (two per pass: every weight record read feeds two rows)
   for (int r0 = t; r0 < N; r0 += 2 * THREADS) {
     const int r1 = r0 + THREADS;
     const bool has1 = r1 < N;
@@ -173,7 +208,10 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     lsum += pyz_hf_row_tail<MC>(a, z0, d2 + r0 * MC, yf, r0);
     if (has1) lsum += pyz_hf_row_tail<MC>(a, z1, d2 + r1 * MC, yf, r1);
   }
+  }
+  if (lap) PYZ_LAP(lap, 1);
   const double loss = pyz_hf_block_sum<WAVES>(lsum, sm);  // also orders d2[] before phase B
+  if (lap) PYZ_LAP(lap, 2);
   PYZ_STAMP(3, 5);
   // ---------------- phase B: lane <-> hidden unit, wave <-> row slice
   {
@@ -202,17 +240,34 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     // widest instantiation, whose 4 x (MI + MC) staged operands do not fit the 128 registers of a 1024-thread
     // workgroup)
     constexpr int RB = (MI + MC > 8) ? 2 : 4;
-    for (int r = rb; r < re; r += RB) {
-      float xv[RB][MI], dv[RB][MC], dsel[RB];
+    // software pipelined: the operands of the next trip are requested before this trip's arithmetic (a trip was three LDS
+    // latencies long: 845 cycles for four rows measured in k_hmc_resident)
+    float xn[RB][MI], dn[RB][MC], dseln[RB];
+    auto fetch = [&](const int r) {
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
-        const int rr = min(r + u, re - 1);
+        const int rr = max(min(r + u, re - 1), rb);   // (an empty slice reads row rb: in range, its terms are switched off)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) xv[u][i] = xs[rr * MI + i];
+        for (int i = 0; i < MI; ++i) xn[u][i] = xs[rr * MI + i];
 #pragma unroll
-        for (int c = 0; c < MC; ++c) dv[u][c] = d2[rr * MC + c];
-        dsel[u] = d2[rr * MC + cbc];
+        for (int c = 0; c < MC; ++c) dn[u][c] = d2[rr * MC + c];
+        dseln[u] = d2[rr * MC + cbc];
       }
+    };
+    constexpr bool PIPE = WAVES <= 4;   // (the 1024-thread kernel has no registers for a second set of operands)
+    if (PIPE && rb < re) fetch(rb);
+    for (int r = rb; r < re; r += RB) {
+      float xv[RB][MI], dv[RB][MC], dsel[RB];
+      if (!PIPE) fetch(r);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) xv[u][i] = xn[u][i];
+#pragma unroll
+        for (int c = 0; c < MC; ++c) dv[u][c] = dn[u][c];
+        dsel[u] = dseln[u];
+      }
+      if (PIPE && r + RB < re) fetch(r + RB);
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const float on = (r + u < re) ? 1.0f : 0.0f;  // rows past the slice contribute nothing
@@ -241,6 +296,7 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     if (is_b2) pw[I * H + H + H * C + cb] = gb2;
   }
   PYZ_STAMP(3, 6);
+  if (lap) PYZ_LAP(lap, 3);
   __syncthreads();
   for (int e = t; e < a.D; e += THREADS) {
     float s = part[e];
@@ -249,6 +305,7 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     g[e] = s;
   }
   __syncthreads();
+  if (lap) PYZ_LAP(lap, 4);
   return loss;
 }
 

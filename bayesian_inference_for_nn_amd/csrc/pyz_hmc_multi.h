@@ -39,6 +39,12 @@ struct HmcMultiArgs {
   float *slab;    // (2, P, NW, D) partial gradients
   double *lpart;  // (2, P, NW) partial sums of the row losses
   float *scal;    // (P, 4): sum p^2 and sum log prior at the start, loss at the start
+  // k_hmc_resident only
+  unsigned *epoch;               // (P) per chain: the tag below which every granule in `gran` is stale (advanced by L + 1 per proposal)
+  unsigned long long *gran;      // (2, P, NW, Dp) {tag, value} granules: the partial gradients (and, in the last two, the loss sum) of a slice
+  int Dp;                        // granules per slice: a multiple of 32, >= D + 2
+  int spin_limit;                // sweeps without progress before a workgroup gives up (stats[7] = -1, q untouched)
+  int diag;                      // PYZ_HMC_DIAG builds only (timing, wrong results): 1 = no exchange, 2 = no gradient evaluation
 };
 
 static inline size_t pyz_hmc_multi_lds_bytes(int max_rows, int MI, int MC, int C, int D, int loss) {
@@ -61,6 +67,22 @@ __device__ __forceinline__ float pyz_hm_slab_sum(const float *sl, const int NW, 
     for (int j = 0; j < 16; ++j) gs += k0 + j < NW ? v[j] : 0.0f;
   }
   return gs;
+}
+
+// The leapfrog arithmetic with its fused multiply-adds written out: k_hmc_multi (+ final) and k_hmc_resident must give the
+// same bits, and left to the compiler the contraction of a * b + c depends on the code around it.
+__device__ __forceinline__ float pyz_hm_dU(const float qv, const float pmean, const float isig2, const float n_train, const float gs) {
+  return __fmaf_rn(n_train, gs, (qv - pmean) * isig2);
+}
+__device__ __forceinline__ float pyz_hm_kick(const float pv, const float k, const float dU) { return __fmaf_rn(-k, dU, pv); }
+__device__ __forceinline__ float pyz_hm_drift(const float qv, const float drift, const float pv) { return __fmaf_rn(drift, pv, qv); }
+__device__ __forceinline__ float pyz_hm_log_prior(const float qv, const float pmean, const float sigma, const float ls) {
+  const float u = (qv - pmean) / sigma;
+  return __fmaf_rn(-0.5f * u, u, -ls) - PYZ_LOG_SQRT_2PI;
+}
+
+__device__ __forceinline__ float pyz_hm_potential(const float sum_log_prior, const float loss, const float n_train) {
+  return __fmaf_rn(loss, n_train, 0.0f - sum_log_prior);   // U = -sum log prior + N * mean loss
 }
 
 // momentum of element e (HMC.py:168-171: p = m z)
@@ -126,8 +148,7 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi(HmcMultiArgs m) {
         q_out[e] = qv;
         p_out[e] = pv;
         sp2 += (double)(pv * pv);
-        const float u = (qv - a.prior_mean) / a.prior_sigma;
-        slp += (double)(-0.5f * u * u - ls - PYZ_LOG_SQRT_2PI);
+        slp += (double)pyz_hm_log_prior(qv, a.prior_mean, a.prior_sigma, ls);
       }
     }
     if (wg == 0) {  // uniform per workgroup
@@ -156,15 +177,10 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi(HmcMultiArgs m) {
         qv = q_in[e];
         pin = p_in[e];
       }
-      const float dU = (qv - a.prior_mean) * isig2 + n_train * gs;
-      float pv, qn;
-      if (m.t == 1) {  // behind the first gradient: half kick (HMC.py:82), then the first drift
-        pv = pin - (eps / 2) * dU;
-        qn = qv + drift * pv;
-      } else {         // kick + drift (HMC.py:84-86)
-        pv = pin - eps * dU;
-        qn = qv + drift * pv;
-      }
+      const float dU = pyz_hm_dU(qv, a.prior_mean, isig2, n_train, gs);
+      // behind the first gradient: half kick (HMC.py:82); behind the others: kick (HMC.py:84-86); then the drift
+      const float pv = pyz_hm_kick(pin, m.t == 1 ? eps / 2 : eps, dU);
+      const float qn = pyz_hm_drift(qv, drift, pv);
       q[e] = qn;
       p[e] = pv;
       if (wg == 0) {
@@ -203,18 +219,12 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi_final(HmcMultiArgs
   for (int e = t; e < D; e += PYZ_HM_THREADS) {
     const float gs = pyz_hm_slab_sum(sl, NW, D, e);
     const float qv = q_in[e];
-    const float dU = (qv - a.prior_mean) * isig2 + n_train * gs;
-    float pv;
-    if (L == 0) {  // the only gradient: both half kicks (HMC.py:82, 87)
-      pv = p_in[e] - (eps / 2) * dU;
-      pv = pv - (eps / 2) * dU;
-    } else {       // last kick and the closing half kick share the last gradient
-      pv = p_in[e] - eps * dU;
-      pv = pv - (eps / 2) * dU;
-    }
+    const float dU = pyz_hm_dU(qv, a.prior_mean, isig2, n_train, gs);
+    // the last kick and the closing half kick share the last gradient (L == 0, the only gradient: both half kicks, HMC.py:82, 87)
+    float pv = pyz_hm_kick(p_in[e], L == 0 ? eps / 2 : eps, dU);
+    pv = pyz_hm_kick(pv, eps / 2, dU);
     sp2 += (double)(pv * pv);
-    const float u = (qv - a.prior_mean) / a.prior_sigma;
-    slp += (double)(-0.5f * u * u - ls - PYZ_LOG_SQRT_2PI);
+    slp += (double)pyz_hm_log_prior(qv, a.prior_mean, a.prior_sigma, ls);
   }
   const float sp2_1 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(sp2, sm);
   const float slp_1 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(slp, sm);
@@ -223,11 +233,9 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi_final(HmcMultiArgs
   for (int k = 0; k < NW; ++k) lv += lp[k];
   const float loss1 = (float)(lv / (double)N);
   const float loss0 = L == 0 ? loss1 : m.scal[chain * 4 + 2];
-  float U0 = 0.0f - m.scal[chain * 4 + 1];
-  U0 = U0 + loss0 * n_train;
+  const float U0 = pyz_hm_potential(m.scal[chain * 4 + 1], loss0, n_train);
   const float K0 = (1.0f / (2.0f * a.m)) * m.scal[chain * 4 + 0];
-  float U1 = 0.0f - slp_1;
-  U1 = U1 + loss1 * n_train;
+  const float U1 = pyz_hm_potential(slp_1, loss1, n_train);
   const float K1 = (1.0f / (2.0f * a.m)) * sp2_1;
   const float lr = K0 + U0 - K1 - U1;
   const bool acc = m.call->burning || (a.uniform[chain] < expf(lr));
@@ -243,5 +251,225 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_multi_final(HmcMultiArgs
     s[5] = K1;
     s[6] = lr;
     s[7] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------- the sliced proposal as ONE launch
+// k_hmc_multi pays a kernel boundary per gradient evaluation (22 launches x 9.4 us at C3).  Here the NW workgroups of a
+// chain stay resident for the whole proposal: the data slice is staged once, q and p live in every workgroup's LDS
+// (each applies the same kick / drift to its own copy), and between two gradient evaluations the workgroups exchange
+// their partial gradients through memory as data-tagged granules (cdna_hip_programming.md, Guideline 16, R2: "the data
+// IS the flag"): element e of slice k of evaluation ph is ONE aligned 8-byte write-through store {tag, value} with
+// tag = the chain's epoch + ph + 1, and a consumer re-reads the granules it needs (sc1 loads) until every tag matches.
+// No counter, no flag, no fence: a store is visible or it is not, and a stale granule has a smaller tag.
+// (A first version followed the counter hand-off -- drain the stores, barrier, atomic add, poll, barrier, sc1 loads --
+// and was no faster than one launch per evaluation: three dependent trips to the fabric per evaluation, 9.3 us.)
+// Granule rows ping-pong by evaluation parity: a workgroup that has consumed evaluation ph + 1 knows that every other
+// one has finished reading evaluation ph.  The chain's epoch lives in device memory and is advanced by workgroup 0 at
+// the end of the proposal (the next launch reads it behind the kernel boundary): tags grow monotonically over the life
+// of the buffer, which is zeroed when it is allocated.
+// The sums keep k_hmc_multi's order (slices 0 .. NW-1), so both forms give the same bits.
+// The grid must be resident at once (the launcher checks NW x chains against the device); a wave whose sweep makes
+// `spin_limit` passes without completing gives up: the proposal is marked (stats[7] = -1), q stays, every workgroup
+// returns -- the grid always drains.
+typedef __attribute__((address_space(1))) unsigned long long pyz_gu64;
+
+__device__ __forceinline__ void pyz_hm_store_granule(unsigned long long *g, const unsigned tag, const float v) {
+  __hip_atomic_store((pyz_gu64 *)g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pyz_hm_load_granule(const unsigned long long *g) {
+  return __hip_atomic_load((pyz_gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MI, int MC, int ACT>
+__global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_resident(HmcMultiArgs m) {
+  extern __shared__ float lds[];
+  const HmcFusedArgs &a = m.f;
+  const int D = a.D, N = a.N, I = a.I, C = a.C, L = a.L, Dp = m.Dp;
+  const int t = threadIdx.x, wg = blockIdx.x, chain = blockIdx.y, P = gridDim.y, NW = m.NW;
+  const int r0 = (int)(((long long)N * wg) / NW), r1 = (int)(((long long)N * (wg + 1)) / NW), nloc = r1 - r0;
+  float *q = lds, *p = q + D, *g = p + D, *part = g + D;
+  float *wj = part + PYZ_HM_WAVES * D, *xs = wj + 64 * (MI + MC + 2), *d2 = xs + m.max_rows * MI, *yf = d2 + m.max_rows * MC;
+  const size_t fl = (size_t)(3 + PYZ_HM_WAVES) * D + (size_t)64 * (MI + MC + 2) + (size_t)m.max_rows * MI +
+                    (size_t)m.max_rows * MC + (size_t)m.max_rows * (a.loss == PYZ_LOSS_MSE ? C : 1);
+  double *sm = reinterpret_cast<double *>(lds + ((fl * 4 + 15) / 16) * 4);
+  int *gave_up = reinterpret_cast<int *>(sm + 32);
+  const long long so = (long long)chain * D;
+  const unsigned epoch0 = m.epoch[chain];   // (written by the previous proposal's launch)
+  // ---- this slice of the data set, once per proposal
+  for (int e = t; e < nloc * MI; e += PYZ_HM_THREADS) {
+    const int r = e / MI, i = e - r * MI;
+    xs[e] = i < I ? a.x[(long long)(r0 + r) * I + i] : 0.0f;
+  }
+  if (a.loss == PYZ_LOSS_SCCE) {
+    for (int e = t; e < nloc; e += PYZ_HM_THREADS) yf[e] = __int_as_float(reinterpret_cast<const int32_t *>(a.y)[r0 + e]);
+  } else {
+    for (int e = t; e < nloc * C; e += PYZ_HM_THREADS) yf[e] = reinterpret_cast<const float *>(a.y)[(long long)r0 * C + e];
+  }
+  // ---- the starting point: q, a fresh momentum, and (workgroup 0) K0 and the prior part of U0
+  const float ls = logf(a.prior_sigma);
+  float sp2_0 = 0.0f, slp_0 = 0.0f;
+  {
+    double sp2 = 0.0, slp = 0.0;
+    const HmcCall call = *m.call;
+    for (int e = t; e < D; e += PYZ_HM_THREADS) {
+      const float qv = a.q[so + e], pv = pyz_hm_momentum(a, call, chain, e);
+      q[e] = qv;
+      p[e] = pv;
+      sp2 += (double)(pv * pv);
+      slp += (double)pyz_hm_log_prior(qv, a.prior_mean, a.prior_sigma, ls);
+    }
+    if (t == 0) *gave_up = 0;
+    if (wg == 0) {  // uniform per workgroup
+      sp2_0 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(sp2, sm);
+      slp_0 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(slp, sm);
+    }
+  }
+  const float eps = a.epsilon, drift = eps / a.m, n_train = (float)N;
+  const float isig2 = 1.0f / (a.prior_sigma * a.prior_sigma);
+  float loss0 = 0.0f, loss1 = 0.0f;
+  double sp2_1 = 0.0, slp_1 = 0.0;
+#ifdef PYZ_STAMPS
+  unsigned long long lap[16] = {0};
+  PYZ_LAP(lap, 8);
+  lap[8] = 0;
+#else
+  unsigned long long *lap = nullptr;
+#endif
+  for (int ph = 0; ph <= L; ++ph) {
+    __syncthreads();
+    PYZ_LAP(lap, 7);
+    const unsigned tag = epoch0 + (unsigned)ph + 1u;
+    // ---- gradient of the mean loss over this slice of the rows, published as granule row (ph & 1, chain, wg)
+    double lsum = 0.0;
+#ifdef PYZ_HMC_DIAG
+    if (!(m.diag & 2))
+#endif
+    lsum = pyz_hf_loss_grad<MI, MC, ACT, PYZ_HM_WAVES>(a, q, g, part, wj, xs, d2, yf, sm, nloc, lap);
+    unsigned long long *row = m.gran + ((((long long)(ph & 1) * P + chain) * NW) + wg) * Dp;
+    const unsigned long long lbits = __builtin_bit_cast(unsigned long long, lsum);
+    for (int e = t; e < Dp; e += PYZ_HM_THREADS) {
+      float v = e < D ? g[e] : 0.0f;
+      if (e == Dp - 2) v = __uint_as_float((unsigned)(lbits & 0xffffffffull));
+      if (e == Dp - 1) v = __uint_as_float((unsigned)(lbits >> 32));
+      if (e < D || e >= Dp - 2) pyz_hm_store_granule(row + e, tag, v);
+    }
+    PYZ_LAP(lap, 5);
+    if (ph == L && wg != 0) return;   // (uniform) only workgroup 0 closes the proposal
+    // ---- element e of the summed gradient: the NW slices in order, sixteen granules per sweep
+    const unsigned long long *rows = m.gran + (((long long)(ph & 1) * P + chain) * NW) * Dp;
+    for (int e0 = 0; e0 < D; e0 += PYZ_HM_THREADS) {
+      const int e = e0 + t;
+      const bool mine = e < D;
+      const int ec = mine ? e : 0;
+      float gs = 0.0f;
+      for (int k0 = 0; k0 < NW; k0 += 16) {
+        float v[16];
+        for (int spins = 0;;) {
+          bool ok = true;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const unsigned long long x = pyz_hm_load_granule(rows + (long long)min(k0 + j, NW - 1) * Dp + ec);
+            v[j] = __uint_as_float((unsigned)x);
+            ok &= (unsigned)(x >> 32) == tag;
+          }
+#ifdef PYZ_HMC_DIAG
+          if (m.diag & 1) ok = true;
+#endif
+          if (__all(ok || !mine)) break;
+          if (++spins > m.spin_limit) {   // (wave-uniform)
+            *gave_up = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gs += k0 + j < NW ? v[j] : 0.0f;
+      }
+      if (mine) {
+        const float qv = q[e];
+        const float dU = pyz_hm_dU(qv, a.prior_mean, isig2, n_train, gs);
+        if (ph == L) {   // the last kick and the closing half kick share the last gradient (L == 0: both half kicks)
+          float pv = pyz_hm_kick(p[e], L == 0 ? eps / 2 : eps, dU);
+          pv = pyz_hm_kick(pv, eps / 2, dU);
+          sp2_1 += (double)(pv * pv);
+          slp_1 += (double)pyz_hm_log_prior(qv, a.prior_mean, a.prior_sigma, ls);
+        } else {         // half kick behind the first gradient (HMC.py:82), kick behind the others (HMC.py:84-86); then the drift
+          const float pv = pyz_hm_kick(p[e], ph == 0 ? eps / 2 : eps, dU);
+          p[e] = pv;
+          q[e] = pyz_hm_drift(qv, drift, pv);
+        }
+      }
+    }
+    PYZ_LAP(lap, 6);
+    if (wg == 0 && (ph == 0 || ph == L) && t < 64) {   // the loss at the starting point (U0) / at the proposal (U1): wave 0
+      // lane k holds slice k's sum (NW <= 32 <= 64 lanes); summed in slice order by lane 0
+      const int k = min(t, NW - 1);
+      unsigned long long lo = 0, hi = 0;
+      for (int spins = 0;;) {
+        lo = pyz_hm_load_granule(rows + (long long)k * Dp + Dp - 2);
+        hi = pyz_hm_load_granule(rows + (long long)k * Dp + Dp - 1);
+        bool ok = (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
+#ifdef PYZ_HMC_DIAG
+        if (m.diag & 1) ok = true;
+#endif
+        if (__all(ok)) break;
+        if (++spins > m.spin_limit) {
+          *gave_up = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const double mine_sum = __builtin_bit_cast(double, ((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull));
+      double v = 0.0;
+      for (int kk = 0; kk < NW; ++kk) v += __shfl(mine_sum, kk, 64);
+      const float lv = (float)(v / (double)N);
+      if (ph == 0) loss0 = lv;
+      if (ph == L) loss1 = lv;
+    }
+    __syncthreads();
+    if (*gave_up) {   // (uniform) the others never showed up: not resident together, or one of them gave up
+      if (t == 0 && wg == 0) {
+        a.stats[chain * 8 + 7] = -1.0f;
+        m.epoch[chain] = epoch0 + (unsigned)L + 1u;
+      }
+      return;
+    }
+  }
+#ifdef PYZ_STAMPS
+  if (t == 0 && chain == 0)
+    for (int k = 0; k < 8; ++k) pyz_dbg_buf[3][0][0][k][0] = lap[k];
+#endif
+  // ---- workgroup 0: energies, Metropolis test, write-back (k_hmc_multi_final)
+  loss0 = __shfl(loss0, 0, 64);   // (lane 0 of wave 0 holds them; thread 0 is the only reader below)
+  loss1 = __shfl(loss1, 0, 64);
+  const float s1 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(sp2_1, sm);
+  const float l1 = (float)pyz_hf_block_sum<PYZ_HM_WAVES>(slp_1, sm);
+  const float U0 = pyz_hm_potential(slp_0, loss0, n_train);
+  const float K0 = (1.0f / (2.0f * a.m)) * sp2_0;
+  const float U1 = pyz_hm_potential(l1, loss1, n_train);
+  const float K1 = (1.0f / (2.0f * a.m)) * s1;
+  const float lr = K0 + U0 - K1 - U1;
+  // every thread needs the decision: thread 0 has the losses, the others get it through LDS
+  if (t == 0) {
+    const bool acc0 = m.call->burning || (a.uniform[chain] < expf(lr));
+    *gave_up = acc0 ? 2 : 0;
+  }
+  __syncthreads();
+  const bool acc = *gave_up == 2;
+  if (acc)
+    for (int e = t; e < D; e += PYZ_HM_THREADS) a.q[so + e] = q[e];
+  if (t == 0) {
+    float *s = a.stats + chain * 8;
+    s[0] = acc ? 1.0f : 0.0f;
+    s[1] = acc ? loss1 : loss0;
+    s[2] = U0;
+    s[3] = K0;
+    s[4] = U1;
+    s[5] = K1;
+    s[6] = lr;
+    s[7] = 0.0f;
+    m.epoch[chain] = epoch0 + (unsigned)L + 1u;
   }
 }

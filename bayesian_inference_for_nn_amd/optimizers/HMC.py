@@ -100,6 +100,9 @@ class HMC(Optimizer):
             return
         self._stream.synchronize()
         all_stats = torch.stack([p[0] for p in self._pending]).cpu().numpy()
+        if (all_stats[:, :, 7] < 0).any():
+            raise RuntimeError("an HMC proposal gave up waiting for its row-slice workgroups (k_hmc_resident: the grid was not "
+                               "resident at once); set PYZ_HMC_RESIDENT=0 for one launch per gradient evaluation")
         for (_, q_snap, sampling), stats in zip(self._pending, all_stats):
             accepted = stats[:, 0] != 0
             if accepted[0]:

@@ -98,7 +98,8 @@ def main():
                               "us_per_sample": round(us, 1), "samples_per_s_per_chain": round(1e6 / us, 1),
                               "samples_per_s_aggregate": round(chains * 1e6 / us, 1),
                               "grad_evals_per_s": round(chains * 21 * 1e6 / us, 1), "accept_rate_timed": round(rate, 3),
-                              "kernel_path": os.environ.get("PYZ_HMC_MULTI", "1") == "1" and chains <= 16 and "k_hmc_multi" or "k_hmc_fused"}))
+                              "kernel_path": os.environ.get("PYZ_HMC_MULTI", "1") == "1" and chains <= 16 and
+                              (os.environ.get("PYZ_HMC_RESIDENT", "1") != "0" and "k_hmc_resident" or "k_hmc_multi") or "k_hmc_fused"}))
     if "c5" in only:   # SVGD 64 particles 784->200->10
         dims = (784, 200, 10)
         spec = engine.MLPSpec(dims, ("relu", "softmax"), "scce")
