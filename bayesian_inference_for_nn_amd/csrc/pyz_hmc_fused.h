@@ -17,6 +17,8 @@
 // relu/tanh/sigmoid/linear, softmax+SCCE or MSE output.  Anything else uses the generic path.
 #pragma once
 
+#include <type_traits>
+
 #include "pyz_common.h"
 #include "pyz_gemm.h"
 #include "pyz_kernels.h"
@@ -115,6 +117,18 @@ __device__ __forceinline__ double pyz_hf_row_tail(const HmcFusedArgs &a, const f
   return (double)(acc / (float)C);
 }
 
+// where element e of the parameter vector sits in the weight records wj (-1: b2, which has no record)
+template <int MI, int MC>
+__device__ __forceinline__ int pyz_hf_wj_slot(const int e, const int I, const int H, const int C) {
+  constexpr int SJ = MI + MC + 2;
+  if (e < I * H) return (e % H) * SJ + e / H;
+  const int e1 = e - I * H;
+  if (e1 < H) return e1 * SJ + MI + MC;
+  const int e2 = e1 - H;
+  if (e2 < H * C) return (e2 / C) * SJ + MI + e2 % C;
+  return -1;
+}
+
 // sum of the row losses over the nloc rows staged in xs / yf, and the gradient of (that sum / N) into
 // g[] at the weights q[] (both LDS).  WAVES = waves of the workgroup (16: the whole data set in one
 // workgroup, k_hmc_fused; 4: a row slice, k_hmc_multi).
@@ -124,40 +138,44 @@ __device__ __forceinline__ double pyz_hf_row_tail(const HmcFusedArgs &a, const f
 template <int MI, int MC, int ACT, int WAVES = PYZ_HF_WAVES>
 __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float *g, float *part, float *wj,
                                    const float *xs, float *d2, const float *yf, double *sm, const int nloc,
-                                   unsigned long long *lap = nullptr) {
+                                   unsigned long long *lap = nullptr, const bool wj_ready = false) {
   constexpr int SJ = MI + MC + 2;
   constexpr int THREADS = 64 * WAVES;
   const int N = nloc, I = a.I, H = a.H, C = a.C;
   const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;  // w scalar: phase B's row slice lives in SGPRs
   const float *W1 = q, *b1 = q + I * H, *W2 = b1 + H, *b2 = W2 + H * C;
-  for (int e = t; e < H * SJ; e += THREADS) {
-    const int j = e / SJ, k = e - j * SJ;
-    float v = 0.0f;
-    if (k < MI) v = k < I ? W1[k * H + j] : 0.0f;
-    else if (k < MI + MC) v = (k - MI) < C ? W2[j * C + (k - MI)] : 0.0f;
-    else if (k == MI + MC) v = b1[j];
-    wj[e] = v;
+  // wj_ready (uniform): the caller keeps the weight records current itself (pyz_hf_wj_slot) and has had a barrier since
+  if (!wj_ready) {
+    for (int e = t; e < H * SJ; e += THREADS) {
+      const int j = e / SJ, k = e - j * SJ;
+      float v = 0.0f;
+      if (k < MI) v = k < I ? W1[k * H + j] : 0.0f;
+      else if (k < MI + MC) v = (k - MI) < C ? W2[j * C + (k - MI)] : 0.0f;
+      else if (k == MI + MC) v = b1[j];
+      wj[e] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (lap) PYZ_LAP(lap, 0);
   // ---------------- phase A
   double lsum = 0.0;
-  if constexpr (WAVES <= 4) {
-    // row slices (a few dozen rows on 256 threads): TWO lanes per row, each takes half of the hidden units, and the two
-    // partial logits are added across the lane pair (a + b on one lane, b + a on the other: the same bits).  One lane per
-    // row leaves most of the workgroup idle behind a loop over all H units (k_hmc_resident: 4 600 of 19 000 cycles
-    // per gradient evaluation).
-    const int half = t & 1, H0 = (H + 1) >> 1;
-    const int jb = half ? H0 : 0, je = half ? H : H0;
-    for (int rbase = 0; rbase < N; rbase += THREADS / 2) {
-      const int r = rbase + (t >> 1);
+  if constexpr (WAVES <= 8) {
+    // row slices (a few dozen rows on 256 / 512 threads): LPR lanes per row, each takes 1 / LPR of the hidden units, and the
+    // partial logits are added across the lanes of a row (pairwise tree; a + b on one lane and b + a on its partner are
+    // the same bits).  One lane per row leaves most of the workgroup idle behind a loop over all H units
+    // (k_hmc_resident: 4 600 of 19 000 cycles per gradient evaluation).
+    constexpr int LPR = WAVES <= 4 ? 2 : 4;
+    const int sub = t & (LPR - 1), Hq = (H + LPR - 1) / LPR;
+    const int jb = min(sub * Hq, H), je = min(jb + Hq, H);
+    for (int rbase = 0; rbase < N; rbase += THREADS / LPR) {
+      const int r = rbase + t / LPR;
       const bool has = r < N;
       const int rc = has ? r : N - 1;   // (spare lanes redo the last row: same values to the same places)
       float x0[MI], z0[MC];
 #pragma unroll
       for (int i = 0; i < MI; ++i) x0[i] = xs[rc * MI + i];
 #pragma unroll
-      for (int c = 0; c < MC; ++c) z0[c] = (half == 0 && c < C) ? b2[c] : 0.0f;
+      for (int c = 0; c < MC; ++c) z0[c] = (sub == 0 && c < C) ? b2[c] : 0.0f;
 #pragma unroll 5
       for (int j = jb; j < je; ++j) {
         const float *rec = wj + j * SJ;
@@ -169,9 +187,12 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
         for (int c = 0; c < MC; ++c) z0[c] = fmaf(h0, rec[MI + c], z0[c]);
       }
 #pragma unroll
-      for (int c = 0; c < MC; ++c) z0[c] = z0[c] + __shfl_xor(z0[c], 1, 64);
+      for (int o = 1; o < LPR; o <<= 1) {
+#pragma unroll
+        for (int c = 0; c < MC; ++c) z0[c] = z0[c] + __shfl_xor(z0[c], o, 64);
+      }
       const double tail = pyz_hf_row_tail<MC>(a, z0, d2 + rc * MC, yf, rc);
-      if (has && half == 0) lsum += tail;
+      if (has && sub == 0) lsum += tail;
     }
   } else {
   // rows (two per pass: every weight record read feeds two rows)
@@ -210,7 +231,13 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
   }
   }
   if (lap) PYZ_LAP(lap, 1);
-  const double loss = pyz_hf_block_sum<WAVES>(lsum, sm);  // also orders d2[] before phase B
+  // the loss: per-wave sums now, the total behind the barrier that follows phase B (pyz_hf_block_sum's values and order, one
+  // barrier less); this barrier also orders d2[] before phase B
+  {
+    const double wsum = pyz_wave_sum(lsum);
+    if (l == 0) sm[w] = wsum;
+  }
+  __syncthreads();
   if (lap) PYZ_LAP(lap, 2);
   PYZ_STAMP(3, 5);
   // ---------------- phase B: lane <-> hidden unit, wave <-> row slice
@@ -235,58 +262,52 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     }
     const float bj = rec[MI + MC];
     const int rb = (int)(((long long)N * w) / WAVES), re = (int)(((long long)N * (w + 1)) / WAVES);
-    // RB rows per trip: their LDS reads are issued together and the dependent chains
-    // (pre -> h -> dh -> dpre) interleave instead of serialising on LDS latency (four rows; two for the
-    // widest instantiation, whose 4 x (MI + MC) staged operands do not fit the 128 registers of a 1024-thread
-    // workgroup)
-    constexpr int RB = (MI + MC > 8) ? 2 : 4;
-    // software pipelined: the operands of the next trip are requested before this trip's arithmetic (a trip was three LDS
-    // latencies long: 845 cycles for four rows measured in k_hmc_resident)
-    float xn[RB][MI], dn[RB][MC], dseln[RB];
-    auto fetch = [&](const int r) {
+    // RB rows per trip: their LDS reads are issued together (one base address, constant offsets) and the dependent chains
+    // (pre -> h -> dh -> dpre) interleave instead of serialising on LDS latency.  Whole trips carry no row masks or clamps;
+    // the rows left over go one at a time.  (k_hmc_resident: a masked, clamped trip of four rows was ~200 instructions,
+    // 6 500 of 17 500 cycles per gradient evaluation.)  Eight rows where the registers allow it (the 256-thread slice
+    // kernels on a narrow model), two for the widest instantiation.
+    constexpr int RB = (MI + MC > 8) ? 2 : ((WAVES <= 8 && MI + MC <= 4) ? 8 : 4);
+    auto row_terms = [&](const float (&xv)[MI], const float (&dv)[MC]) {
+      float pre = bj, dh = 0.0f;
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int rr = max(min(r + u, re - 1), rb);   // (an empty slice reads row rb: in range, its terms are switched off)
+      for (int i = 0; i < MI; ++i) pre = fmaf(xv[i], w1[i], pre);
+      const float h = pyz_act(pre, ACT);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) xn[u][i] = xs[rr * MI + i];
+      for (int c = 0; c < MC; ++c) {
+        gw2[c] = fmaf(h, dv[c], gw2[c]);
+        dh = fmaf(w2[c], dv[c], dh);
+      }
+      const float dpre = dh * pyz_act_grad(h, ACT);
 #pragma unroll
-        for (int c = 0; c < MC; ++c) dn[u][c] = d2[rr * MC + c];
-        dseln[u] = d2[rr * MC + cbc];
+      for (int i = 0; i < MI; ++i) gw1[i] = fmaf(xv[i], dpre, gw1[i]);
+      gb1 += dpre;
+      float dsel = dv[0];   // lanes H .. H+C-1: column cb of delta_out
+#pragma unroll
+      for (int c = 1; c < MC; ++c) dsel = cbc == c ? dv[c] : dsel;
+      gb2 += dsel;
+    };
+    int r = rb;
+    auto trips = [&](auto nrows) {   // whole trips of R rows, in row order
+      constexpr int R = decltype(nrows)::value;
+      for (; r + R <= re; r += R) {
+        float xv[R][MI], dv[R][MC];
+        const float *xr = xs + r * MI, *dr = d2 + r * MC;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) xv[u][i] = xr[u * MI + i];
+#pragma unroll
+          for (int c = 0; c < MC; ++c) dv[u][c] = dr[u * MC + c];
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) row_terms(xv[u], dv[u]);
       }
     };
-    constexpr bool PIPE = WAVES <= 4;   // (the 1024-thread kernel has no registers for a second set of operands)
-    if (PIPE && rb < re) fetch(rb);
-    for (int r = rb; r < re; r += RB) {
-      float xv[RB][MI], dv[RB][MC], dsel[RB];
-      if (!PIPE) fetch(r);
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) xv[u][i] = xn[u][i];
-#pragma unroll
-        for (int c = 0; c < MC; ++c) dv[u][c] = dn[u][c];
-        dsel[u] = dseln[u];
-      }
-      if (PIPE && r + RB < re) fetch(r + RB);
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const float on = (r + u < re) ? 1.0f : 0.0f;  // rows past the slice contribute nothing
-        float pre = bj, dh = 0.0f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) pre = fmaf(xv[u][i], w1[i], pre);
-        const float h = pyz_act(pre, ACT) * on;
-#pragma unroll
-        for (int c = 0; c < MC; ++c) {
-          gw2[c] = fmaf(h, dv[u][c], gw2[c]);
-          dh = fmaf(w2[c], dv[u][c], dh);
-        }
-        const float dpre = dh * pyz_act_grad(h, ACT) * on;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) gw1[i] = fmaf(xv[u][i], dpre, gw1[i]);
-        gb1 += dpre;
-        gb2 += dsel[u] * on;
-      }
-    }
+    trips(std::integral_constant<int, RB>());
+    if constexpr (RB > 4) trips(std::integral_constant<int, 4>());
+    if constexpr (RB > 2) trips(std::integral_constant<int, 2>());
+    trips(std::integral_constant<int, 1>());
     float *pw = part + w * a.D;
     if (is_h) {
       for (int i = 0; i < I; ++i) pw[i * H + j] = gw1[i];
@@ -298,6 +319,10 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
   PYZ_STAMP(3, 6);
   if (lap) PYZ_LAP(lap, 3);
   __syncthreads();
+  double loss = 0.0;
+#pragma unroll
+  for (int i = 0; i < WAVES; ++i) loss += sm[i];
+  asm volatile("" : "+v"(loss));   // (pinned here: see pyz_hf_block_sum)
   for (int e = t; e < a.D; e += THREADS) {
     float s = part[e];
 #pragma unroll

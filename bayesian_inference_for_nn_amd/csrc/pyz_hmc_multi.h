@@ -16,8 +16,10 @@
 
 #include "pyz_hmc_fused.h"
 
-#define PYZ_HM_THREADS 256
+#ifndef PYZ_HM_WAVES
 #define PYZ_HM_WAVES 4
+#endif
+#define PYZ_HM_THREADS (64 * PYZ_HM_WAVES)
 #define PYZ_HM_MAXW 32
 
 // what changes from proposal to proposal lives in device memory (uploaded with the uniforms), so
@@ -337,8 +339,8 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_resident(HmcMultiArgs m)
 #else
   unsigned long long *lap = nullptr;
 #endif
+  __syncthreads();
   for (int ph = 0; ph <= L; ++ph) {
-    __syncthreads();
     PYZ_LAP(lap, 7);
     const unsigned tag = epoch0 + (unsigned)ph + 1u;
     // ---- gradient of the mean loss over this slice of the rows, published as granule row (ph & 1, chain, wg)
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_resident(HmcMultiArgs m)
 #ifdef PYZ_HMC_DIAG
     if (!(m.diag & 2))
 #endif
-    lsum = pyz_hf_loss_grad<MI, MC, ACT, PYZ_HM_WAVES>(a, q, g, part, wj, xs, d2, yf, sm, nloc, lap);
+    lsum = pyz_hf_loss_grad<MI, MC, ACT, PYZ_HM_WAVES>(a, q, g, part, wj, xs, d2, yf, sm, nloc, lap, ph > 0);
     unsigned long long *row = m.gran + ((((long long)(ph & 1) * P + chain) * NW) + wg) * Dp;
     const unsigned long long lbits = __builtin_bit_cast(unsigned long long, lsum);
     for (int e = t; e < Dp; e += PYZ_HM_THREADS) {
@@ -397,8 +399,11 @@ __global__ void __launch_bounds__(PYZ_HM_THREADS) k_hmc_resident(HmcMultiArgs m)
           slp_1 += (double)pyz_hm_log_prior(qv, a.prior_mean, a.prior_sigma, ls);
         } else {         // half kick behind the first gradient (HMC.py:82), kick behind the others (HMC.py:84-86); then the drift
           const float pv = pyz_hm_kick(p[e], ph == 0 ? eps / 2 : eps, dU);
+          const float qn = pyz_hm_drift(qv, drift, pv);
           p[e] = pv;
-          q[e] = pyz_hm_drift(qv, drift, pv);
+          q[e] = qn;
+          const int slot = pyz_hf_wj_slot<MI, MC>(e, I, a.H, C);   // the next evaluation finds its weight records current
+          if (slot >= 0) wj[slot] = qn;
         }
       }
     }
