@@ -299,7 +299,8 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
     g.nblk = grid_batch;  // one loss partial per row
     m->cur_nblk = g.nblk;
     // rows per wave: four when the launch has tens of thousands of rows (many particles), else one
-    const int RW = (long long)P * grid_batch >= 32768 ? 4 : 1;
+    static const int rw_rows = pyz_env_int("PYZ_HEAD_RW_ROWS", 32768);
+    const int RW = (long long)P * grid_batch >= rw_rows ? 4 : 1;
     const dim3 grid((unsigned)cdiv(cdiv(grid_batch, RW), 4), P), block(256);
 #define PYZ_HEAD_ROWS_CASE(U, C)                                                               \
   if (UT == U && NP == C) {                                                                    \
@@ -551,6 +552,11 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess)
       return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs) failed"));
+    const int gr_lds = (int)pyz_svgd_gram_lds_bytes();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gram_tile) failed"));
   }
   *out = m;
   return PYZ_OK;
@@ -1537,17 +1543,23 @@ static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, 
   const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
   const bool gram = gram_on && mfma_f64_layout_ok(st);
   if (gram) {
-    PYZ_LAUNCH(k_svgd_gram_tile, dim3(L.td.nblk), dim3(256), 0, st, L.td);
+    // a shard whose rows lie in one or two row blocks of 16 computes those blocks only; every other row range takes the
+    // 10 upper blocks of the whole matrix (identical bits per entry, pyz_kernels.h)
+    const int rb_lo = L.td.row0 >> 4, rb_hi = (L.td.row0 + L.td.n_local - 1) >> 4;
+    const size_t gr_lds = pyz_svgd_gram_lds_bytes();
+    if (rb_hi == rb_lo) PYZ_LAUNCH((k_svgd_gram_tile<1, false>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
+    else if (rb_hi == rb_lo + 1) PYZ_LAUNCH((k_svgd_gram_tile<2, false>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
+    else PYZ_LAUNCH((k_svgd_gram_tile<4, true>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
   } else {
     L.td.diag = nullptr;
     PYZ_LAUNCH(k_svgd_dist_tile, dim3(L.td.nblk), dim3(256), 0, st, L.td);
   }
   L.ta.diag = L.td.diag;
   if (median) {
-    PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(256), 0, st, L.td, 1);   // distances only
+    PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(1024), 0, st, L.td, 1);   // distances only
     PYZ_LAUNCH(k_svgd_median, dim3(1), dim3(1024), 0, st, L.td);
   }
-  PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(256), 0, st, L.ta, 0);
+  PYZ_LAUNCH(k_svgd_kmat, dim3(n_local), dim3(1024), 0, st, L.ta, 0);
   PYZ_LAUNCH_CHECK();
   m->km_valid = true;
   m->km_all = d_all;

@@ -727,7 +727,7 @@ struct SvgdTileArgs {
   double *kmat;            // (n_local, 64) kernel values (0 past M)
   float *ksum;             // (n_local) sum_j K_ij, float (the factor of the loss gradient)
   double *ksumd;           // (n_local) the same row sum in float64, in the update kernel's summation order
-  double *diag;            // Gram form only: (nblk, 64) partial squared norms of all particles; else nullptr
+  double *diag;            // (unused since round 3: the Gram form leaves partial squared distances like the pairwise form)
   // median-heuristic bandwidth (SVGD.py:165-181) only: the squared distances of ALL pairs and the bandwidth they give
   double *dmat;            // (M, 64) squared distances (0 past M), or nullptr
   double *gamma_dev;       // [1] gamma = 1 / (2 h^2) = log(M + 1) / median(d), or nullptr: the fixed `gamma`
@@ -853,27 +853,49 @@ __global__ void k_probe_mfma_f64(int *out) {  // out[0..255]: row of D[r] per la
   }
 }
 
-__global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
-  constexpr int RS = 65;   // row stride (floats) of the staged slab: odd, so that a wave's transposing writes spread over the banks
-  __shared__ double gbuf[(PYZ_SV_E * RS + 1) / 2];               // the 64 x 64 Gram at the end (4 096 doubles) ...
-  float *xs = reinterpret_cast<float *>(gbuf);                   // ... and the staged slab [element][particle] before
+// LDS-only barrier: __syncthreads() also waits for every global load in flight (the fence in it is not address-space
+// aware); the kernels below keep loads in flight across their barriers on purpose.
+__device__ __forceinline__ void pyz_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Eight waves; a slab is 128 elements of all 64 particles.  Lanes run along the ELEMENTS when fetching (two consecutive ones
+// per lane: 512 contiguous bytes of one row per load instruction, wave w brings particles w, w + 8, ...; lane = particle,
+// 64 rows 636 KB apart per instruction, read at 1.4 TB/s), the slab is transposed into LDS ([element][particle]), wave w
+// multiplies elements 16 w .. 16 w + 15 of it (four reduction steps of 4).  Two slabs are in flight in registers and the
+// LDS slab is double-buffered: ONE LDS-only barrier per slab.  (Round 2's form -- four waves, one slab in flight, two
+// __syncthreads per slab, always the 10 blocks of the whole matrix -- took 31 us at C5 whatever the number of local rows:
+// one wave per SIMD waiting for its own loads.)
+//   SYM       the 10 blocks of 16 x 16 on and above the diagonal, mirrored (G is symmetric bit for bit): any row range
+//   NRB 1 / 2 a shard whose local rows lie in one / two row blocks of 16: only those blocks x all four column blocks
+// Every G_ij is the same sequence of matrix instructions and the same fixed-order sum over the waves in all forms, so a
+// shard's rows equal the whole matrix's bit for bit.  The squared norms are summed on the vector ALU (the diagonal
+// blocks are not computed by a shard).
+#define PYZ_GRAM_RS 65   // row stride (floats) of a staged slab: odd, so that a wave's transposing writes spread over the banks
+#define PYZ_GRAM_SLAB (PYZ_SV_E * PYZ_GRAM_RS)
+static inline size_t pyz_svgd_gram_lds_bytes() { return 65536 + 16384 + 512; }   // epilogue: 8 waves x 4 blocks x 256 doubles + the norms' partials + the norms
+static_assert(2 * PYZ_GRAM_SLAB * sizeof(float) <= 65536 + 16384, "slabs fit");
+
+template <int NRB, bool SYM>
+__global__ void __launch_bounds__(512) k_svgd_gram_tile(SvgdTileArgs g) {
+  extern __shared__ double gram_lds[];
+  float *const xs0 = reinterpret_cast<float *>(gram_lds);
+  float *const xs1 = xs0 + PYZ_GRAM_SLAB;
+  constexpr int RS = PYZ_GRAM_RS;
+  constexpr int NR = SYM ? 4 : NRB;
   const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;
   const long long base = (long long)blockIdx.x * g.range;
-  pyz_f64x4 acc[4][4];
+  const int rb_lo = SYM ? 0 : g.row0 >> 4;   // uniform
+  pyz_f64x4 acc[NR][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NR; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = pyz_f64x4{0.0, 0.0, 0.0, 0.0};
-  // Lanes run along the ELEMENTS (two consecutive ones per lane), the particles over the instructions: wave w brings
-  // particles w, w + 4, ... -- 512 contiguous bytes of one row per load, the access k_svgd_gs streams the matrix with.
-  // (Lane = particle, 64 rows 636 KB apart per instruction, read this slab at 1.4 TB/s and made the kernel 48 us
-  // for 11 us of matrix instructions.)  The next slab is requested before the matrix instructions of the current one.
+  double nrm[4] = {0.0, 0.0, 0.0, 0.0};
   const bool pair_ok = (g.D % 2 == 0) && ((reinterpret_cast<uintptr_t>(g.all) & 7) == 0);   // every row 8-byte aligned
-  auto fetch = [&](const long long e0, float2 (&v)[16]) {
+  auto fetch = [&](const long long e0, float2 (&v)[8]) {
     const long long d = e0 + 2 * l;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int j = w + 4 * u;   // wave-uniform
+    for (int u = 0; u < 8; ++u) {
+      const int j = w + 8 * u;   // wave-uniform
       const float *p = g.all + (long long)min(j, g.M - 1) * g.D + d;
       if (j < g.M && pair_ok && d + 1 < g.D) {
         v[u] = *reinterpret_cast<const float2 *>(p);
@@ -883,66 +905,125 @@ __global__ void __launch_bounds__(256) k_svgd_gram_tile(SvgdTileArgs g) {
       }
     }
   };
-  const int n_slabs = g.range / PYZ_SV_E;
-  float2 v[16];
-  PYZ_STAMP(4, 0);
-  if (base < g.D) fetch(base, v);
-  for (int ps = 0; ps < n_slabs; ++ps) {
-    const long long e0 = base + (long long)ps * PYZ_SV_E;
-    if (e0 >= g.D) break;  // uniform
+  int n_slabs = 0;
+  if (base < g.D) {
+    const long long left = (g.D - base + PYZ_SV_E - 1) / PYZ_SV_E;
+    n_slabs = (int)min((long long)(g.range / PYZ_SV_E), left);
+  }
+  auto body = [&](float2 (&v)[8], float *xs, const int ps) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      xs[(2 * l) * RS + w + 4 * u] = v[u].x;
-      xs[(2 * l + 1) * RS + w + 4 * u] = v[u].y;
+    for (int u = 0; u < 8; ++u) {
+      xs[(2 * l) * RS + w + 8 * u] = v[u].x;
+      xs[(2 * l + 1) * RS + w + 8 * u] = v[u].y;
     }
-    __syncthreads();
-    if (ps + 1 < n_slabs && e0 + PYZ_SV_E < g.D) fetch(e0 + PYZ_SV_E, v);
+    pyz_lds_barrier();
+    if (ps + 2 < n_slabs) fetch(base + (long long)(ps + 2) * PYZ_SV_E, v);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const float *xe = xs + (32 * w + 4 * ks + (l >> 4)) * RS;
+    for (int ks = 0; ks < 4; ++ks) {
+      const float *xe = xs + (16 * w + 4 * ks + (l >> 4)) * RS;
       double a[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) a[b] = (double)xe[(l & 15) + 16 * b];
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+      for (int b = 0; b < 4; ++b) nrm[b] = fma(a[b], a[b], nrm[b]);
+      if constexpr (SYM) {
 #pragma unroll
-        for (int cb = rb; cb < 4; ++cb)   // G is symmetric bit for bit: the 10 blocks on and above the diagonal
-          acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], a[cb], acc[rb][cb], 0, 0, 0);
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int cb = rb; cb < 4; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], a[cb], acc[rb][cb], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+          const int rb = rb_lo + r;   // uniform
+          const double ar = rb == 0 ? a[0] : rb == 1 ? a[1] : rb == 2 ? a[2] : a[3];
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[r][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, a[cb], acc[r][cb], 0, 0, 0);
+        }
+      }
     }
+  };
+  float2 v0[8], v1[8];
+  PYZ_STAMP(4, 0);
+  if (n_slabs > 0) fetch(base, v0);
+  if (n_slabs > 1) fetch(base + PYZ_SV_E, v1);
+  for (int ps = 0; ps < n_slabs; ps += 2) {
+    body(v0, xs0, ps);
     if (ps == 0) PYZ_STAMP(4, 1);
-    __syncthreads();
+    if (ps + 1 < n_slabs) body(v1, xs1, ps + 1);
   }
   PYZ_STAMP(4, 2);
-  // the four waves' partial Grams, added in wave order (the slab is dead: its storage holds G now)
-  for (int ww = 0; ww < 4; ++ww) {
-    if (w == ww) {
+  // ---- the eight waves' partial Grams, four blocks per round through LDS, summed in wave order by the thread that stores
+  //      the element; then the norms (32 partials per particle: wave-major, reduction lane minor)
+  double *const red = gram_lds;                 // [8 waves][4 blocks][256]
+  double *const nred = gram_lds + 8 * 4 * 256;  // [8 waves * 4 lanes][64]
+  double *const nsum = nred + 32 * 64;          // [64] squared norms over the workgroup's elements
+  constexpr int NBLK = SYM ? 10 : 4 * NRB;
+  pyz_lds_barrier();   // the last slab's fragment reads are done
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+  for (int b = 0; b < 4; ++b) nred[(4 * w + (l >> 4)) * 64 + 16 * b + (l & 15)] = nrm[b];
+  pyz_lds_barrier();
+  if (t < 64) {
+    double s = nred[t];
 #pragma unroll
-        for (int cb = rb; cb < 4; ++cb)
+    for (int q = 1; q < 32; ++q) s += nred[q * 64 + t];
+    nsum[t] = s;
+  }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gi = 16 * rb + (l >> 4) + 4 * r, gj = 16 * cb + (l & 15);
-            const double vsum = (ww == 0 ? 0.0 : gbuf[gi * 64 + gj]) + acc[rb][cb][r];
-            gbuf[gi * 64 + gj] = vsum;
-            if (cb != rb) gbuf[gj * 64 + gi] = vsum;   // the mirrored block
-          }
+  for (int r0 = 0; r0 < NBLK; r0 += 4) {
+    if (r0) pyz_lds_barrier();   // the previous round's sums have been read
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bi = r0 + q;   // compile-time block number: (rb, cb) of the 10 upper blocks in row-major order, or (r, cb)
+      if (bi >= NBLK) break;
+      int rb, cb;
+      if constexpr (SYM) {
+        rb = bi < 4 ? 0 : bi < 7 ? 1 : bi < 9 ? 2 : 3;
+        cb = bi < 4 ? bi : bi < 7 ? bi - 3 : bi < 9 ? bi - 5 : 3;
+      } else {
+        rb = bi >> 2;
+        cb = bi & 3;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(w * 4 + q) * 256 + r * 64 + l] = acc[rb][cb][r];
     }
-    __syncthreads();
+    pyz_lds_barrier();   // (the first round's also publishes nsum)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = t + 512 * h, q = e >> 8, r = (e >> 6) & 3, ll = e & 63;
+      const int bi = r0 + q;
+      if (bi < NBLK) {
+        int rb, cb;
+        if (SYM) {
+          rb = bi < 4 ? 0 : bi < 7 ? 1 : bi < 9 ? 2 : 3;
+          cb = bi < 4 ? bi : bi < 7 ? bi - 3 : bi < 9 ? bi - 5 : 3;
+        } else {
+          rb = rb_lo + (bi >> 2);
+          cb = bi & 3;
+        }
+        double s = red[q * 256 + r * 64 + ll];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) s += red[(ww * 4 + q) * 256 + r * 64 + ll];
+        const int gi = 16 * rb + (ll >> 4) + 4 * r, gj = 16 * cb + (ll & 15);
+        // this block's share of the squared distance, |x_i|^2 + |x_j|^2 - 2 x_i . x_j (symmetric bit for bit): what the
+        // pairwise form leaves in `part` too, so k_svgd_kmat sums one kind of partial
+        s = (nsum[gi] + nsum[gj]) - 2.0 * s;
+        const int il = gi - g.row0, jl = gj - g.row0;
+        if (il >= 0 && il < g.n_local) g.part[((long long)il * g.nblk + blockIdx.x) * 64 + gj] = s;
+        if (SYM && cb != rb && jl >= 0 && jl < g.n_local) g.part[((long long)jl * g.nblk + blockIdx.x) * 64 + gi] = s;
+      }
+    }
   }
   PYZ_STAMP(4, 3);
-  for (int e = t; e < g.n_local * 64; e += 256) {
-    const int il = e >> 6, j = e & 63;
-    g.part[((long long)il * g.nblk + blockIdx.x) * 64 + j] = gbuf[(g.row0 + il) * 64 + j];
-  }
-  if (t < 64) g.diag[(long long)blockIdx.x * 64 + t] = gbuf[t * 64 + t];
-  PYZ_STAMP(4, 4);
 }
 
 // dist_only != 0: the squared distances of the row go to g.dmat and nothing else happens (first half of the
 // median-heuristic path); with g.dmat set and dist_only == 0 the distances are read from there.
-__global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
-  __shared__ double sl[4][64], sg[4][64];
+__global__ void __launch_bounds__(1024) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
+  // sixteen waves per row: wave q sums blocks q, q + 16, ... (all of a wave's loads of up to 256 blocks in ONE round trip;
+  // four waves with eight loads in flight each took eight dependent trips, 12 us for a 64-value row), the sixteen sums
+  // combined as a fixed balanced tree
+  __shared__ double sl[16][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
   double d;
   if (g.dmat && !dist_only) {
@@ -950,31 +1031,23 @@ __global__ void __launch_bounds__(256) k_svgd_kmat(SvgdTileArgs g, const int dis
     d = g.dmat[(g.row0 + il) * 64 + j];
   } else {
     const double *pp = g.part + (long long)il * g.nblk * 64 + j;
-    double s = 0.0, sn = 0.0;
-    for (int b0 = q; b0 < g.nblk; b0 += 32) {
-      double v[8], n[8];
+    double s = 0.0;
+    for (int b0 = q; b0 < g.nblk; b0 += 256) {
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v[u] = b0 + 4 * u < g.nblk ? pp[(long long)(b0 + 4 * u) * 64] : 0.0;
-        n[u] = (g.diag && b0 + 4 * u < g.nblk) ? g.diag[(long long)(b0 + 4 * u) * 64 + j] : 0.0;
-      }
+      for (int u = 0; u < 16; ++u) v[u] = b0 + 16 * u < g.nblk ? pp[(long long)(b0 + 16 * u) * 64] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        s += v[u];
-        sn += n[u];
-      }
+      for (int u = 0; u < 16; ++u) s += v[u];
     }
     sl[q][j] = s;
-    sg[q][j] = sn;
     __syncthreads();
     if (q != 0) return;
-    d = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]);
-    if (g.diag) {  // Gram form: the partials are inner products; d_ij = |x_i|^2 + |x_j|^2 - 2 x_i . x_j (d_ii = 0 exactly)
-      const int i = g.row0 + il;
-      const double nj = (sg[0][j] + sg[1][j]) + (sg[2][j] + sg[3][j]);
-      const double ni = (sg[0][i] + sg[1][i]) + (sg[2][i] + sg[3][i]);
-      d = (j == i) ? 0.0 : fmax((ni + nj) - 2.0 * d, 0.0);
-    }
+    const double s0 = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]), s1 = (sl[4][j] + sl[5][j]) + (sl[6][j] + sl[7][j]);
+    const double s2 = (sl[8][j] + sl[9][j]) + (sl[10][j] + sl[11][j]), s3 = (sl[12][j] + sl[13][j]) + (sl[14][j] + sl[15][j]);
+    // (the Gram form's partials are |x_i|^2 + |x_j|^2 - 2 x_i . x_j over a block's elements, by cancellation: the diagonal
+    //  is set to its exact value and the sum kept non-negative; the pairwise form's partials are sums of squares, its
+    //  diagonal exact zeros -- both lines leave them unchanged)
+    d = (j == g.row0 + il) ? 0.0 : fmax((s0 + s1) + (s2 + s3), 0.0);
     if (dist_only) {
       g.dmat[(g.row0 + il) * 64 + j] = j < g.M ? d : 0.0;
       return;
@@ -1123,7 +1196,6 @@ static inline size_t pyz_svgd_gs_lds_bytes() { return sizeof(double) * (64 * PYZ
 
 // LDS-only workgroup barrier: __syncthreads() also waits for the global loads in flight (one counter for loads
 // and stores on this target), which would serialise the phases below
-__device__ __forceinline__ void pyz_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifdef PYZ_STAMPS
 #define PYZ_GS_STAMP(slot) do { if (g.i == 32) PYZ_STAMP(3, slot); } while (0)   // one mid-sweep launch
