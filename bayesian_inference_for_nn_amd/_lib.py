@@ -58,6 +58,8 @@ SIGNATURES = {
     "pyz_svgd_gradients": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, _p]),
     "pyz_svgd_sweep": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _f, _f, _i64, C.c_int, _p, _p]),
     "pyz_svgd_kernel_matrix": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _f, _p]),
+    "pyz_svgd_gram_groups": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "pyz_svgd_kernel_matrix_groups": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, _f, _p]),
     "pyz_svgd_combine": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, C.c_int, _p, _p, _f, _f, _i64, _p, _p]),
     "pyz_predict": (C.c_int, [_p, _p, C.c_int, _p, C.c_int, _p, _p, _p]),
     "pyz_sample_normal_rows": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _p, _u64, _u32, _u32, _p]),

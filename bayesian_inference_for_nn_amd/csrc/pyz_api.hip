@@ -1527,7 +1527,26 @@ static int svgd_check_rows(const pyz_mlp *m, int n_local, int n_total, int row0,
   return PYZ_OK;
 }
 
-static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma, hipStream_t st) {
+// the distance pass over blocks [blk0, blk0 + n_blocks) of the layout (partials of td's rows into the plan's scratch)
+static void svgd_launch_distance_pass(SvgdTileArgs td, int blk0, int n_blocks, bool gram, hipStream_t st) {
+  td.blk0 = blk0;
+  if (gram) {
+    // a shard whose rows lie in one or two row blocks of 16 computes those blocks only; every other row range takes the
+    // 10 upper blocks of the whole matrix (identical bits per entry, pyz_kernels.h)
+    const int rb_lo = td.row0 >> 4, rb_hi = (td.row0 + td.n_local - 1) >> 4;
+    const size_t gr_lds = pyz_svgd_gram_lds_bytes();
+    if (rb_hi == rb_lo) PYZ_LAUNCH((k_svgd_gram_tile<1, false>), dim3(n_blocks), dim3(512), gr_lds, st, td);
+    else if (rb_hi == rb_lo + 1) PYZ_LAUNCH((k_svgd_gram_tile<2, false>), dim3(n_blocks), dim3(512), gr_lds, st, td);
+    else PYZ_LAUNCH((k_svgd_gram_tile<4, true>), dim3(n_blocks), dim3(512), gr_lds, st, td);
+  } else {
+    PYZ_LAUNCH(k_svgd_dist_tile, dim3(n_blocks), dim3(256), 0, st, td);
+  }
+}
+
+// d_groups != nullptr: the group sums of the partial squared distances of ALL rows, gathered from the ranks that each
+// summed some groups (pyz_svgd_gram_groups); nullptr: this device runs the whole distance pass itself
+static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma,
+                                   const double *d_groups, hipStream_t st) {
   int rc = svgd_check_rows(m, n_local, n_total, row0, gamma);
   if (rc) return rc;
   if (!d_all) return pyz_fail(PYZ_E_INVALID, "null device pointer");
@@ -1538,23 +1557,13 @@ static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, 
   m->km_valid = false;
   TileLayout L;
   if ((rc = svgd_tile_layout(m, d_all, n_total, row0, n_local, gamma, L))) return rc;
-  // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
-  // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
-  const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
-  const bool gram = gram_on && mfma_f64_layout_ok(st);
-  if (gram) {
-    // a shard whose rows lie in one or two row blocks of 16 computes those blocks only; every other row range takes the
-    // 10 upper blocks of the whole matrix (identical bits per entry, pyz_kernels.h)
-    const int rb_lo = L.td.row0 >> 4, rb_hi = (L.td.row0 + L.td.n_local - 1) >> 4;
-    const size_t gr_lds = pyz_svgd_gram_lds_bytes();
-    if (rb_hi == rb_lo) PYZ_LAUNCH((k_svgd_gram_tile<1, false>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
-    else if (rb_hi == rb_lo + 1) PYZ_LAUNCH((k_svgd_gram_tile<2, false>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
-    else PYZ_LAUNCH((k_svgd_gram_tile<4, true>), dim3(L.td.nblk), dim3(512), gr_lds, st, L.td);
-  } else {
-    L.td.diag = nullptr;
-    PYZ_LAUNCH(k_svgd_dist_tile, dim3(L.td.nblk), dim3(256), 0, st, L.td);
+  L.ta.groups = L.td.groups = d_groups;
+  if (!d_groups) {
+    // distances through the Gram matrix on the float64 matrix cores when the instruction's lane layout is the
+    // one the kernel assumes (probed once); else the pairwise float64 VALU kernel
+    const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);  // read per call: tests flip it
+    svgd_launch_distance_pass(L.td, 0, L.td.nblk, gram_on && mfma_f64_layout_ok(st), st);
   }
-  L.ta.diag = L.td.diag;
   if (median) {
     PYZ_LAUNCH(k_svgd_kmat, dim3(n_total), dim3(1024), 0, st, L.td, 1);   // distances only
     PYZ_LAUNCH(k_svgd_median, dim3(1), dim3(1024), 0, st, L.td);
@@ -1567,6 +1576,27 @@ static int svgd_kernel_matrix_impl(pyz_mlp *m, const float *d_all, int n_total, 
   m->km_row0 = row0;
   m->km_local = n_local;
   m->km_gamma = gamma;
+  return PYZ_OK;
+}
+
+// the distance pass of groups [g_lo, g_hi) of the PYZ_SVGD_GROUPS groups of blocks (this rank's share of the ELEMENTS),
+// all rows; the group sums go to the caller's (PYZ_SVGD_GROUPS, 64, 64) buffer at the groups' places
+static int svgd_gram_groups_impl(pyz_mlp *m, const float *d_all, int n_total, int g_lo, int g_hi, double *d_groups, hipStream_t st) {
+  if (!m) return pyz_fail(PYZ_E_INVALID, "null plan");
+  if (!d_all || !d_groups) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n_total < 4 || n_total > 64 || n_total % 4 != 0) return pyz_fail(PYZ_E_INVALID, "the grouped distance pass takes 4 .. 64 particles in multiples of four");
+  if (g_lo < 0 || g_hi > PYZ_SVGD_GROUPS || g_lo >= g_hi) return pyz_fail(PYZ_E_INVALID, "groups [%d, %d) outside [0, %d)", g_lo, g_hi, PYZ_SVGD_GROUPS);
+  m->km_valid = false;
+  TileLayout L;
+  // (the layout of the WHOLE matrix: partials of all rows; gamma does not enter the distance pass)
+  int rc = svgd_tile_layout(m, d_all, n_total, 0, n_total, 1.0f, L);
+  if (rc) return rc;
+  const int nblk = L.td.nblk, nb8 = cdiv(nblk, PYZ_SVGD_GROUPS);
+  const int blk0 = std::min(g_lo * nb8, nblk), blk1 = std::min(g_hi * nb8, nblk);
+  const int gram_on = pyz_env_int("PYZ_SVGD_GRAM", 1);
+  if (blk1 > blk0) svgd_launch_distance_pass(L.td, blk0, blk1 - blk0, gram_on && mfma_f64_layout_ok(st), st);
+  PYZ_LAUNCH(k_svgd_group_reduce, dim3(n_total, g_hi - g_lo), dim3(128), 0, st, (const double *)L.td.part, nblk, g_lo, d_groups);
+  PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }
 
@@ -1625,7 +1655,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
                                    "and particle / local-row counts in multiples of four");
   if (tile_ok && (tiles_on || median)) {
     // every row from the same snapshot: the particle matrix is read once per pass (k_svgd_*_tile)
-    if ((rc = svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, st))) return rc;
+    if ((rc = svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, nullptr, st))) return rc;
     return svgd_combine_impl(m, d_particles, n_local, d_all, n_total, row0, d_adam_m, d_adam_v, lr, gamma, t, d_loss, st);
   }
   const int nblk = cdiv(m->D, PYZ_SVGD_BLOCK_ELEMS);  // one float64 partial per workgroup of k_svgd_dist
@@ -1708,7 +1738,17 @@ int pyz_svgd_sweep(pyz_mlp *m, float *d_particles, int n_local, const float *d_a
 }
 
 int pyz_svgd_kernel_matrix(pyz_mlp *m, const float *d_all, int n_total, int row0, int n_local, float gamma, void *stream) {
-  return svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, as_stream(stream));
+  return svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, nullptr, as_stream(stream));
+}
+
+int pyz_svgd_gram_groups(pyz_mlp *m, const float *d_all, int n_total, int g_lo, int g_hi, double *d_groups, void *stream) {
+  return svgd_gram_groups_impl(m, d_all, n_total, g_lo, g_hi, d_groups, as_stream(stream));
+}
+
+int pyz_svgd_kernel_matrix_groups(pyz_mlp *m, const double *d_groups, const float *d_all, int n_total, int row0, int n_local,
+                                  float gamma, void *stream) {
+  if (!d_groups) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  return svgd_kernel_matrix_impl(m, d_all, n_total, row0, n_local, gamma, d_groups, as_stream(stream));
 }
 
 int pyz_svgd_combine(pyz_mlp *m, float *d_particles, int n_local, const float *d_all, int n_total, int row0,

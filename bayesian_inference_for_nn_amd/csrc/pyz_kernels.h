@@ -736,7 +736,39 @@ struct SvgdTileArgs {
   // loss_out[0] = sum_i loss_in[i] / M over the local particles (k_svgd_loss), or nullptr
   const float *loss_in;
   float *loss_out;
+  // the distance pass split over the ELEMENTS (ranks of a sharded run each take some of the PYZ_SVGD_GROUPS groups of
+  // consecutive blocks): blk0 = global number of the launch's first block; groups = (PYZ_SVGD_GROUPS, 64, 64) group sums of
+  // the partials gathered from all ranks (k_svgd_kmat then reads them instead of `part`), or nullptr
+  int blk0;
+  const double *groups;
 };
+
+// The partial squared distances of the nblk blocks are summed in PYZ_SVGD_GROUPS groups of consecutive blocks, each group
+// as two interleaved halves in block order, the groups as a balanced tree: ONE order whether a device sums all groups
+// itself (k_svgd_kmat) or receives some of them from other ranks (k_svgd_group_reduce there, then k_svgd_kmat).
+// (PYZ_SVGD_GROUPS: include/pyz.h)
+__device__ __forceinline__ double pyz_svgd_half_sum(const double *pp, const int b_lo, const int b_hi, const int h) {
+  double s = 0.0;
+  for (int b0 = b_lo + h; b0 < b_hi; b0 += 32) {   // all loads of up to 32 blocks per group in one round trip
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = b0 + 2 * u < b_hi ? pp[(long long)(b0 + 2 * u) * 64] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  return s;
+}
+
+// group sums of rows [0, n_rows) for groups [g_lo, g_lo + gridDim.y): out[(g * 64 + i) * 64 + j]
+__global__ void __launch_bounds__(128) k_svgd_group_reduce(const double *part, const int nblk, const int g_lo, double *out) {
+  __shared__ double sh[64];
+  const int i = blockIdx.x, g8 = g_lo + blockIdx.y, j = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int nb8 = (nblk + PYZ_SVGD_GROUPS - 1) / PYZ_SVGD_GROUPS, b_lo = g8 * nb8, b_hi = min(b_lo + nb8, nblk);
+  const double s = pyz_svgd_half_sum(part + (long long)i * nblk * 64 + j, b_lo, b_hi, h);
+  if (h == 1) sh[j] = s;
+  __syncthreads();
+  if (h == 0) out[((long long)g8 * 64 + i) * 64 + j] = s + sh[j];
+}
 
 __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
   __shared__ float xs[PYZ_SV_E][64];
@@ -757,7 +789,8 @@ __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
     active = ti < 16 && 4 * tj < g.M;  // (ti <= tj: the row block is inside the matrix too)
     if (!active) ti = tj = 0;
   }
-  const long long base = (long long)blockIdx.x * g.range;
+  const int blk = blockIdx.x + g.blk0;
+  const long long base = (long long)blk * g.range;
   const bool vec_ok = (g.D % 4 == 0);
   double acc[4][4];
 #pragma unroll
@@ -814,14 +847,14 @@ __global__ void __launch_bounds__(256) k_svgd_dist_tile(SvgdTileArgs g) {
   if (active) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      double *o = g.part + ((long long)(4 * ti + a) * g.nblk + blockIdx.x) * 64 + 4 * tj;
+      double *o = g.part + ((long long)(4 * ti + a) * g.nblk + blk) * 64 + 4 * tj;
 #pragma unroll
       for (int b = 0; b < 4; ++b) o[b] = acc[a][b];
     }
     if (whole && ti != tj) {  // the mirrored block: rows 4 tj .. 4 tj + 3 < M (M is a multiple of 4 here)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        double *o = g.part + ((long long)(4 * tj + b) * g.nblk + blockIdx.x) * 64 + 4 * ti;
+        double *o = g.part + ((long long)(4 * tj + b) * g.nblk + blk) * 64 + 4 * ti;
 #pragma unroll
         for (int a = 0; a < 4; ++a) o[a] = acc[a][b];
       }
@@ -882,7 +915,8 @@ __global__ void __launch_bounds__(512) k_svgd_gram_tile(SvgdTileArgs g) {
   constexpr int RS = PYZ_GRAM_RS;
   constexpr int NR = SYM ? 4 : NRB;
   const int t = threadIdx.x, w = pyz_wave_id(), l = t & 63;
-  const long long base = (long long)blockIdx.x * g.range;
+  const int blk = blockIdx.x + g.blk0;
+  const long long base = (long long)blk * g.range;
   const int rb_lo = SYM ? 0 : g.row0 >> 4;   // uniform
   pyz_f64x4 acc[NR][4];
 #pragma unroll
@@ -1009,8 +1043,8 @@ __global__ void __launch_bounds__(512) k_svgd_gram_tile(SvgdTileArgs g) {
         // pairwise form leaves in `part` too, so k_svgd_kmat sums one kind of partial
         s = (nsum[gi] + nsum[gj]) - 2.0 * s;
         const int il = gi - g.row0, jl = gj - g.row0;
-        if (il >= 0 && il < g.n_local) g.part[((long long)il * g.nblk + blockIdx.x) * 64 + gj] = s;
-        if (SYM && cb != rb && jl >= 0 && jl < g.n_local) g.part[((long long)jl * g.nblk + blockIdx.x) * 64 + gi] = s;
+        if (il >= 0 && il < g.n_local) g.part[((long long)il * g.nblk + blk) * 64 + gj] = s;
+        if (SYM && cb != rb && jl >= 0 && jl < g.n_local) g.part[((long long)jl * g.nblk + blk) * 64 + gi] = s;
       }
     }
   }
@@ -1020,9 +1054,9 @@ __global__ void __launch_bounds__(512) k_svgd_gram_tile(SvgdTileArgs g) {
 // dist_only != 0: the squared distances of the row go to g.dmat and nothing else happens (first half of the
 // median-heuristic path); with g.dmat set and dist_only == 0 the distances are read from there.
 __global__ void __launch_bounds__(1024) k_svgd_kmat(SvgdTileArgs g, const int dist_only) {
-  // sixteen waves per row: wave q sums blocks q, q + 16, ... (all of a wave's loads of up to 256 blocks in ONE round trip;
-  // four waves with eight loads in flight each took eight dependent trips, 12 us for a 64-value row), the sixteen sums
-  // combined as a fixed balanced tree
+  // sixteen waves per row: wave q sums one half of group q / 2 (all of a wave's loads in ONE round trip; four waves with
+  // eight loads in flight each took eight dependent trips, 12 us for a 64-value row); groups gathered from other ranks
+  // (g.groups) replace the sums over `part`
   __shared__ double sl[16][64];
   const int il = blockIdx.x, j = threadIdx.x & 63, q = threadIdx.x >> 6;
   double d;
@@ -1030,20 +1064,18 @@ __global__ void __launch_bounds__(1024) k_svgd_kmat(SvgdTileArgs g, const int di
     if (q != 0) return;
     d = g.dmat[(g.row0 + il) * 64 + j];
   } else {
-    const double *pp = g.part + (long long)il * g.nblk * 64 + j;
-    double s = 0.0;
-    for (int b0 = q; b0 < g.nblk; b0 += 256) {
-      double v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = b0 + 16 * u < g.nblk ? pp[(long long)(b0 + 16 * u) * 64] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
+    if (g.groups) {
+      if (q < PYZ_SVGD_GROUPS) sl[q][j] = g.groups[((long long)q * 64 + g.row0 + il) * 64 + j];
+    } else {
+      const int nb8 = (g.nblk + PYZ_SVGD_GROUPS - 1) / PYZ_SVGD_GROUPS, b_lo = (q >> 1) * nb8, b_hi = min(b_lo + nb8, g.nblk);
+      sl[q][j] = pyz_svgd_half_sum(g.part + (long long)il * g.nblk * 64 + j, b_lo, b_hi, q & 1);
     }
-    sl[q][j] = s;
     __syncthreads();
     if (q != 0) return;
-    const double s0 = (sl[0][j] + sl[1][j]) + (sl[2][j] + sl[3][j]), s1 = (sl[4][j] + sl[5][j]) + (sl[6][j] + sl[7][j]);
-    const double s2 = (sl[8][j] + sl[9][j]) + (sl[10][j] + sl[11][j]), s3 = (sl[12][j] + sl[13][j]) + (sl[14][j] + sl[15][j]);
+    double sg[PYZ_SVGD_GROUPS];
+#pragma unroll
+    for (int u = 0; u < PYZ_SVGD_GROUPS; ++u) sg[u] = g.groups ? sl[u][j] : sl[2 * u][j] + sl[2 * u + 1][j];
+    const double s0 = sg[0] + sg[1], s1 = sg[2] + sg[3], s2 = sg[4] + sg[5], s3 = sg[6] + sg[7];
     // (the Gram form's partials are |x_i|^2 + |x_j|^2 - 2 x_i . x_j over a block's elements, by cancellation: the diagonal
     //  is set to its exact value and the sum kept non-negative; the pairwise form's partials are sums of squares, its
     //  diagonal exact zeros -- both lines leave them unchanged)

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from ._lib import ACT, LOSS, SWEEP, check, ptr
 
+SVGD_GROUPS = 8   # PYZ_SVGD_GROUPS of include/pyz.h
+
 
 @dataclass(frozen=True)
 class MLPSpec:
@@ -368,6 +370,25 @@ class MLPPlan:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
         check(self.lib.pyz_svgd_kernel_matrix(self.h, ptr(all_particles), all_particles.shape[0], int(row0), int(n_local),
                                               _gamma(gamma), st))
+
+    def svgd_gram_groups(self, all_particles, g_lo, g_hi, groups, stream=None):
+        """The distance pass over groups [g_lo, g_hi) of the SVGD_GROUPS groups of element blocks, all pairs: the group sums
+        go to rows [g_lo, g_hi) of `groups` (SVGD_GROUPS, 64 * 64) float64 (a rank's share of a D-sharded pass)."""
+        _f32(all_particles, name="all_particles")
+        assert all_particles.dim() == 2 and all_particles.shape[1] == self.D
+        assert groups.dtype == torch.float64 and groups.is_cuda and groups.is_contiguous() and groups.numel() == SVGD_GROUPS * 4096
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+        check(self.lib.pyz_svgd_gram_groups(self.h, ptr(all_particles), all_particles.shape[0], int(g_lo), int(g_hi),
+                                            ptr(groups), st))
+
+    def svgd_kernel_matrix_groups(self, groups, all_particles, row0, n_local, gamma, stream=None):
+        """svgd_kernel_matrix from the complete group sums (every rank's svgd_gram_groups, gathered) instead of a pass over
+        the snapshot; same bits."""
+        _f32(all_particles, name="all_particles")
+        assert groups.dtype == torch.float64 and groups.is_cuda and groups.is_contiguous() and groups.numel() == SVGD_GROUPS * 4096
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+        check(self.lib.pyz_svgd_kernel_matrix_groups(self.h, ptr(groups), ptr(all_particles), all_particles.shape[0], int(row0),
+                                                     int(n_local), _gamma(gamma), st))
 
     def svgd_combine(self, particles, all_particles, row0, adam_m, adam_v, lr, gamma, t, loss_out):
         """Second half: phi, Adam and the loss of every local row; after svgd_gradients AND svgd_kernel_matrix.

@@ -66,6 +66,14 @@ class SVGD(Optimizer):
         # overlap_kernel_matrix: the kernel matrix of the snapshot (a function of the particles alone, SVGD.py:183-202) on a
         # second stream while the gradient pass runs (SVGD.py:104-111); only the combine waits for both
         self._overlap_km = bool(kwargs.get("overlap_kernel_matrix", os.environ.get("PYZ_SVGD_OVERLAP_KM", "1") == "1"))
+        # shard_gram: the distance pass of the kernel matrix split over the ELEMENTS -- each rank sums the groups of blocks
+        # that are its share (D / world of the gathered matrix instead of all of it) and the ranks exchange 8 / world x 32 KB
+        # (a second, small all-gather per step); needs a world that divides 8.  Same bits as the local pass (pyz.h).
+        # Off by default: on ONE GPU standing in for a rank of eight it measured no faster (the local pass
+        # already hides behind the gradient kernels; what is lost there is lost to the cross-stream waits), and it has not
+        # run on a multi-GPU node.  PYZ_SVGD_SHARD_GRAM=1 or the kwarg opts in.
+        self._shard_gram = (bool(kwargs.get("shard_gram", os.environ.get("PYZ_SVGD_SHARD_GRAM", "0") == "1"))
+                            and self._sharded and 8 % world == 0 and self._M % 4 == 0 and self._M <= 64)
         # every rank draws the same batches and the same particle initialisation: one base seed for all
         self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local, chain_per_rank=False)
         self._rank, self._world = rank, world
@@ -89,6 +97,11 @@ class SVGD(Optimizer):
         self._adam_v = torch.zeros((self._n_local, self._D), device="cuda")
         self._loss_dev = torch.zeros(1, device="cuda")
         self._aux = None
+        if self._shard_gram:
+            per = 8 // world
+            self._g_lo, self._g_hi = rank * per, (rank + 1) * per
+            self._groups = torch.zeros((8, 64 * 64), dtype=torch.float64, device="cuda")
+            self._groups_local = torch.zeros((per, 64 * 64), dtype=torch.float64, device="cuda") if world > 1 else None
         vx, vy = self._dataset.valid_data.as_numpy()
         self._val_n = len(vx)
         if self._val_n > 0:
@@ -105,6 +118,18 @@ class SVGD(Optimizer):
         if self._aux is None:
             self._aux = torch.cuda.Stream()
         return self._aux
+
+    def _kernel_matrix_from_groups(self, snapshot, aux):
+        """The kernel matrix with the distance pass sharded over the elements: this rank's groups, the exchange of the group
+        sums (all ranks' collectives in program order: the particle gather of this step came first), K rows from all groups."""
+        import torch
+        from .. import parallel
+        with torch.cuda.stream(aux):
+            self._plan.svgd_gram_groups(snapshot, self._g_lo, self._g_hi, self._groups, stream=aux)
+            if self._groups_local is not None:
+                self._groups_local.copy_(self._groups[self._g_lo:self._g_hi])
+                parallel.all_gather_rows(self._groups_local, self._groups)
+            self._plan.svgd_kernel_matrix_groups(self._groups, snapshot, self._row0, self._n_local, self._gamma, stream=aux)
 
     def step(self, save_document_path=None):
         import torch
@@ -131,7 +156,10 @@ class SVGD(Optimizer):
                     work.wait()                                 # the aux stream waits for the gather ...
             else:
                 aux.wait_stream(main)                           # ... or for what wrote the snapshot
-            self._plan.svgd_kernel_matrix(snapshot, self._row0, self._n_local, self._gamma, stream=aux)
+            if self._shard_gram:
+                self._kernel_matrix_from_groups(snapshot, aux)
+            else:
+                self._plan.svgd_kernel_matrix(snapshot, self._row0, self._n_local, self._gamma, stream=aux)
             done = aux.record_event()
             self._plan.svgd_gradients(cur, self._x_dev, self._y_dev, batch=b, row_idx=idx)
             main.wait_event(done)

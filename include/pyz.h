@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYZ_VERSION 300 /* 0.3.0 */
+#define PYZ_VERSION 301 /* 0.3.1 */
 
 #define PYZ_OK 0
 #define PYZ_E_INVALID (-1) /* bad argument / unsupported combination */
@@ -266,6 +266,22 @@ int pyz_svgd_kernel_matrix(pyz_mlp *mlp, const float *d_all, int n_total, int ro
 int pyz_svgd_combine(pyz_mlp *mlp, float *d_particles, int n_local, const float *d_all, int n_total, int row0,
                      float *d_adam_m, float *d_adam_v, float lr, float gamma, int64_t t, float *d_loss,
                      void *stream);
+
+/* The distance pass of pyz_svgd_kernel_matrix split over the ELEMENTS of the particles, for sharded runs (each
+ * rank reads D / world of the gathered matrix instead of all of it; the exchange is PYZ_SVGD_GROUPS x 32 KB, the caller's):
+ * the blocks of the pass form PYZ_SVGD_GROUPS groups of consecutive blocks;
+ *   pyz_svgd_gram_groups           partial squared distances of ALL pairs over groups [g_lo, g_hi) of d_all (M, D), M a multiple
+ *                                  of four <= 64, summed per group into d_groups[(g * 64 + i) * 64 + j] (float64; entries of
+ *                                  other groups are not touched) -- rank r of a world that divides 8 takes groups
+ *                                  [8 r / world, 8 (r + 1) / world) and all-gathers its slice;
+ *   pyz_svgd_kernel_matrix_groups  pyz_svgd_kernel_matrix with the complete d_groups (PYZ_SVGD_GROUPS, 64, 64) in place of the
+ *                                  pass over d_all (still named: pyz_svgd_combine checks it).
+ * pyz_svgd_kernel_matrix sums its own partials in the same order (groups, then a fixed tree over the groups), so both
+ * routes give the same bits for any split of the groups over ranks (SVGD.py:183-202 per pair, float64). */
+#define PYZ_SVGD_GROUPS 8
+int pyz_svgd_gram_groups(pyz_mlp *mlp, const float *d_all, int n_total, int g_lo, int g_hi, double *d_groups, void *stream);
+int pyz_svgd_kernel_matrix_groups(pyz_mlp *mlp, const double *d_groups, const float *d_all, int n_total, int row0,
+                                  int n_local, float gamma, void *stream);
 
 /* ---- R1: BayesianModel.predict (BayesianModel.py:106-129): S weight draws
  * d_weights (S, D) -> d_samples (S, n, out) with NaN -> 0, d_mean (n, out). */

@@ -55,8 +55,10 @@ def _scenario(rank, world):
 
     # ---- SVGD, particles sharded 4 + 4, seed=None
     opt = SVGD()
-    opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3))
+    opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3),
+                shard_gram=True)
     assert (opt._world, opt._n_local, opt._row0, opt._sweep) == (2, 4, 4 * rank, "jacobi")
+    assert opt._shard_gram and (opt._g_lo, opt._g_hi) == (4 * rank, 4 * rank + 4)   # the distance pass split over the elements
     out["svgd_seed"] = opt._seed
     out["svgd_init"] = opt._all.cpu().numpy().tolist()
     rows = []

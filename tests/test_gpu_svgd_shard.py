@@ -175,6 +175,51 @@ def test_c5_one_rank_of_eight(eng):
     plan.close()
 
 
+@pytest.mark.parametrize("case", ["c5_rank7_of_8", "small_gamma", "small_median", "small_pairwise"])
+def test_kernel_matrix_from_group_sums_equals_the_local_pass(eng, case, monkeypatch):
+    """The distance pass split over the ELEMENTS (pyz_svgd_gram_groups on slices of the groups, as ranks of a world of 2, 4
+    or 8 would, then pyz_svgd_kernel_matrix_groups) against pyz_svgd_kernel_matrix on the same snapshot: bit for bit through
+    the combine, whatever the split of the groups."""
+    if case == "c5_rank7_of_8":
+        spec, M, row0, nl, gamma = MNIST, 64, 56, 8, 1.0
+        x, y = synth.mnist_like(256)
+        rng = np.random.default_rng(5)
+        parts = (synth.glorot_uniform(spec.dims)[None, :] + 1e-3 * rng.normal(size=(M, spec.n_params))).astype(np.float32)
+        splits = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8)]
+    else:
+        spec, row0, nl = WIDE3, 4, 8
+        x, y, parts = _wide3_case(M=20)
+        M = 20
+        gamma = "median" if case == "small_median" else 1.0
+        splits = [(0, 4), (4, 8)] if case != "small_pairwise" else [(0, 2), (2, 4), (4, 6), (6, 8)]
+        if case == "small_pairwise":
+            monkeypatch.setenv("PYZ_SVGD_GRAM", "0")
+    D, n = spec.n_params, len(x)
+    plan = eng.MLPPlan(espec(eng, spec), max_batch=n, max_particles=nl)
+    xd, yd, snap = dev(x), dev(y, torch.int32), dev(parts)
+    outs = []
+    for form in ("local", "groups"):
+        local = snap[row0:row0 + nl].clone()
+        am, av = torch.full((nl, D), 0.01, device="cuda"), torch.full((nl, D), 0.02, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        plan.svgd_gradients(local, xd, yd)
+        if form == "local":
+            plan.svgd_kernel_matrix(snap, row0, nl, gamma)
+        else:
+            groups = torch.full((eng.SVGD_GROUPS, 64 * 64), float("nan"), dtype=torch.float64, device="cuda")
+            for g_lo, g_hi in reversed(splits):          # (any order: every call fills its own groups)
+                plan.svgd_gram_groups(snap, g_lo, g_hi, groups)
+            torch.cuda.synchronize()
+            assert torch.isfinite(groups.view(8, 64, 64)[:, :M, :M]).all()
+            plan.svgd_kernel_matrix_groups(groups, snap, row0, nl, gamma)
+        plan.svgd_combine(local, snap, row0, am, av, 1e-3, gamma, 2, loss)
+        torch.cuda.synchronize()
+        outs.append((local.clone(), am.clone(), av.clone(), loss.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    plan.close()
+
+
 # ------------------------------------------------------------------ RCCL in a world of one rank
 def _free_port():
     s = socket.socket()
@@ -205,6 +250,7 @@ def _nccl_world_of_one(rank, port, ret):
         for name, kw in (("whole", dict(shard=False, sweep="jacobi")),
                          ("gather_sync", dict(_force_sharded=True, overlap_gather=False)),
                          ("gather_async", dict(_force_sharded=True, overlap_gather=True)),
+                         ("gather_sync_sharded_gram", dict(_force_sharded=True, overlap_gather=False, shard_gram=True)),
                          ("gather_async_one_stream", dict(_force_sharded=True, overlap_gather=True, overlap_kernel_matrix=False))):
             opt = SVGD()
             opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3),
@@ -225,7 +271,7 @@ def test_sharded_step_over_rccl_in_a_world_of_one(gpu_device):
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
     mp.spawn(_nccl_world_of_one, args=(_free_port(), ret), nprocs=1, join=True)
-    assert ret["backend"] == "nccl" and ret["sharded_flags"] == [False, True, True, True]
+    assert ret["backend"] == "nccl" and ret["sharded_flags"] == [False, True, True, True, True]
     # gather (synchronous, or asynchronous on RCCL's stream with the wait in front of its first reader), kernel matrix on a
     # second stream, combine: the particles of the unsharded Jacobi run, bit for bit
     assert all(v == 0.0 for v in ret["diff"].values()), dict(ret["diff"])

@@ -175,6 +175,22 @@ def main():
                 main.wait_event(done)
                 plan.svgd_combine(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss)
 
+            # the distance pass sharded over the elements too (SVGD.step with shard_gram): this rank's share of the groups,
+            # the other ranks' group sums standing in the buffer already (no exchange: compute only)
+            per = max(1, 8 * n_local // M)
+            groups = torch.zeros((8, 64 * 64), dtype=torch.float64, device=dev)
+            plan.svgd_gram_groups(allp, 0, 8, groups)
+
+            def step_overlapped_groups():
+                main = torch.cuda.current_stream()
+                aux.wait_stream(main)
+                plan.svgd_gram_groups(allp, 0, per, groups, stream=aux)
+                plan.svgd_kernel_matrix_groups(groups, allp, 0, n_local, 1.0, stream=aux)
+                done = aux.record_event()
+                grad()
+                main.wait_event(done)
+                plan.svgd_combine(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss)
+
             def step_sequential():
                 grad()
                 sweep()
@@ -183,13 +199,20 @@ def main():
             us_s = timed(sweep, 30)
             us_seq = timed(step_sequential, 30)
             us_ovl = timed(step_overlapped, 30)
+            us_grp = timed(step_overlapped_groups, 30)
             with engine.KernelProbe(64) as kp:
                 grad()
                 sweep()
+            with engine.KernelProbe(64) as kp2:
+                plan.svgd_gram_groups(allp, 0, per, groups)
+                plan.svgd_kernel_matrix_groups(groups, allp, 0, n_local, 1.0)
+                plan.svgd_combine(local, allp, 0, am, av, 0.01, 1.0, k[0] + 1, loss)
             print(json.dumps({"config": f"C5 SVGD one rank of {M // n_local}: {n_local} local particles of 64, B=1024 (compute only, no gather)",
                               "gradients_us": round(us_g, 1), "sweep_us": round(us_s, 1), "step_sequential_us": round(us_seq, 1),
                               "step_kernel_matrix_on_second_stream_us": round(us_ovl, 1),
-                              "kernels_us": [(n, round(v, 1)) for n, v in kp.launches]}))
+                              "step_distance_pass_sharded_over_elements_us": round(us_grp, 1),
+                              "kernels_us": [(n, round(v, 1)) for n, v in kp.launches],
+                              "kernels_us_sharded_distance_pass": [(n, round(v, 1)) for n, v in kp2.launches]}))
 
 if __name__ == "__main__":
     main()
