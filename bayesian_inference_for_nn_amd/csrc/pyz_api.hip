@@ -36,6 +36,8 @@ struct Extra {  // lazily sized buffers kept beside the plan
   size_t hm_cap = 0;
   void *hm_res_buf = nullptr;  // k_hmc_resident: per-chain epochs and the granule rows
   size_t hm_res_cap = 0;
+  void *gs_res_buf = nullptr;  // k_svgd_gs_resident: epoch, fail flag, granules of the partials and of the kernel row
+  size_t gs_res_cap = 0;
   hipGraph_t hm_graph = nullptr;  // the launch sequence of one sliced HMC proposal
   hipGraphExec_t hm_exec = nullptr;
   unsigned long long hm_key = 0;
@@ -552,6 +554,9 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, gs_lds) != hipSuccess)
       return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs) failed"));
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs_resident), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)pyz_svgd_gs_res_lds_bytes()) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs_resident) failed"));
     const int gr_lds = (int)pyz_svgd_gram_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
@@ -572,7 +577,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->x.hm_res_buf, m->nonfinite};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->x.hm_res_buf, m->x.gs_res_buf, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) {
@@ -1704,7 +1709,45 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       double *pp[2] = {full(m)->x.part2, full(m)->x.part2 + n_part};
       const size_t gs_lds = pyz_svgd_gs_lds_bytes();
       // (k_svgd_gs's 130 KB of dynamic LDS: allowed when the plan was created, pyz_mlp_create)
-      static const int zigzag = pyz_env_int("PYZ_SVGD_GS_ZIGZAG", 1);   // alternate the row direction from launch to launch
+      // the whole sweep as ONE resident launch when its workgroups fit the chip at once (k_svgd_gs_resident); read per
+      // call: tests flip it
+      const int gs_reducers = cdiv(n_total, 8);   // workgroups that only sum columns of partials (k_svgd_gs_resident)
+      bool resident = pyz_env_int("PYZ_SVGD_GS_RESIDENT", 1) != 0 && ga.nblk + gs_reducers <= pyz_cu_count();
+      if (resident) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_svgd_gs_resident), 256,
+                                                         pyz_svgd_gs_res_lds_bytes()) != hipSuccess || per_cu < 1)
+          resident = false;
+      }
+      if (resident) {
+        pyz_mlp_full *fm = full(m);
+        const size_t gbytes = 256 + sizeof(unsigned long long) * 2 * (2 * (size_t)256 * 64 + 2 * 64);
+        const size_t had = fm->x.gs_res_cap;
+        if ((rc = ensure_bytes(&fm->x.gs_res_buf, &fm->x.gs_res_cap, gbytes, m))) return rc;
+        if (fm->x.gs_res_cap != had)   // a fresh buffer: epoch and tags start at zero (the kernel's tags are >= 1 and only grow)
+          PYZ_HIP(hipMemsetAsync(fm->x.gs_res_buf, 0, fm->x.gs_res_cap, st));
+        unsigned char *gb = static_cast<unsigned char *>(fm->x.gs_res_buf);
+        SvgdGsResArgs ra{};
+        ra.all = d_particles;
+        ra.adam_m = d_adam_m;
+        ra.adam_v = d_adam_v;
+        ra.grad = m->grad;
+        ra.D = m->D;
+        ra.M = n_total;
+        ra.lr_t = a.lr_t;
+        ra.gamma = gamma;
+        ra.nblk = ga.nblk;
+        ra.epoch = reinterpret_cast<unsigned *>(gb);
+        ra.fail = reinterpret_cast<int *>(gb + 64);
+        ra.kgran = reinterpret_cast<unsigned long long *>(gb + 256);
+        ra.pgran = ra.kgran + 2 * 64 * 2;
+        ra.spin_limit = pyz_env_int("PYZ_SVGD_GS_SPIN_LIMIT", 1 << 20);
+        PYZ_LAUNCH(k_svgd_gs_resident, dim3(ga.nblk + gs_reducers), dim3(256), pyz_svgd_gs_res_lds_bytes(), st, ra);
+        PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss, ra.fail, m->nonfinite);
+        PYZ_LAUNCH_CHECK();
+        return PYZ_OK;
+      }
+      const int zigzag = pyz_env_int("PYZ_SVGD_GS_ZIGZAG", 1);   // alternate the row direction from launch to launch (read per call)
       for (int i = -1; i < n_total; ++i) {
         ga.i = i;
         ga.part_in = pp[(i + 2) & 1];   // what launch i - 1 wrote
@@ -1720,7 +1763,7 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       }
     }
   }
-  PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss);
+  PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss, (int *)nullptr, m->nonfinite);
   PYZ_LAUNCH_CHECK();
   return PYZ_OK;
 }

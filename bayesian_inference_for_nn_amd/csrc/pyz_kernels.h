@@ -1192,6 +1192,18 @@ __global__ void __launch_bounds__(256) k_svgd_update_tile(SvgdTileArgs g, const 
   }
 }
 
+// phi of one element and the legacy Adam step on it (SVGD.py:66-67,113; Appendix A3), with every rounding spelled out:
+// k_svgd_gs and k_svgd_gs_resident must give the same bits, and left to itself the compiler fuses multiply-adds
+// differently in the two kernels.
+__device__ __forceinline__ void pyz_svgd_gs_adam(const float ksum, const float gi, const double rep, const float gamma, const int M,
+                                                 const float xi, const float lr_t, float &m, float &v, float &xn) {
+#pragma clang fp contract(off)
+  const float phi = (ksum * gi + (float)(rep * (2.0 * (double)gamma))) / (float)M;
+  m = m + (phi - m) * (1.0f - 0.9f);
+  v = v + (phi * phi - v) * (1.0f - 0.999f);
+  xn = xi - lr_t * m / (sqrtf(v) + 1e-7f);
+}
+
 // ---------------------------------------------------------------- Gauss-Seidel sweep, one launch per particle
 // The reference updates the particles one after the other, each against the rows already updated
 // (SVGD.py:110-120).  With the per-row kernels above that is two launches per particle, each reading the whole
@@ -1348,7 +1360,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
       const double df = in[q] ? (double)xnext[q] - (double)x[j][q] : 0.0;
-      a += df * df;
+      a = fma(df, df, a);
     }
     asm volatile("" : "+v"(a)::"memory");
     acc[j] = a;
@@ -1369,17 +1381,15 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     // row i -- difference 0 -- and underflowed rows add exactly 0)
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
-      const float phi = (ksum * gi[q] + (float)(rep[q] * (2.0 * (double)g.gamma))) / (float)M;
-      const float m = am[q] + (phi - am[q]) * (1.0f - 0.9f);
-      const float v = av[q] + (phi * phi - av[q]) * (1.0f - 0.999f);
-      const float xn = xi[q] - g.lr_t * m / (sqrtf(v) + 1e-7f);
+      float m = am[q], v = av[q], xn;
+      pyz_svgd_gs_adam(ksum, gi[q], rep[q], g.gamma, M, xi[q], g.lr_t, m, v, xn);
       if (in[q]) {
         const long long o = (long long)i * D + e[q];
         g.adam_m[o] = m;
         g.adam_v[o] = v;
         g.all[o] = xn;
         const double df = (double)xnext[q] - (double)xn;
-        acc_i += df * df;
+        acc_i = fma(df, df, acc_i);
       }
     }
   }
@@ -1401,11 +1411,295 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   PYZ_GS_STAMP(7);
 }
 
-// d_loss[0] = sum_i loss_i / M   (SVGD.py:125)
-__global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out) {
+// ---------------------------------------------------------------- Gauss-Seidel sweep, ONE launch for all particles
+// k_svgd_gs reads the whole matrix once per particle (64 x 40.7 MB at C5, 14.4 us per launch).  Here the workgroups stay
+// resident for the sweep: each loads its 768 elements of all rows into registers ONCE and keeps them current (row i is
+// patched when it is updated); per particle the workgroups exchange 64 partial squared distances through memory as
+// data-tagged granules (k_hmc_resident's hand-off: one aligned 8-byte write-through store {tag, half of a double}; the
+// consumer re-reads until the tags are the step's), in two hops:
+//   every workgroup publishes its block's partials of row i + 1 (after updating row i);
+//   the reducer of column j (one of cdiv(M, 8) extra workgroups that own no elements, eight columns each: a reducer wave that
+//   also carried a slice's arithmetic held every step back by its own) sums the nblk partials of d_{i+1,j} in k_svgd_gs's
+//   order, takes K_{i+1,j} = exp(-gamma d) and publishes it; every workgroup's first wave polls the 64 kernel values.
+// Everything else is k_svgd_gs<false>'s arithmetic in its order, so both forms give the same bits (with the per-launch
+// form's rows in ascending order: PYZ_SVGD_GS_ZIGZAG=0).  The partials of row i + 1 against the rows that do not change
+// are taken BEFORE the wait for K_i.  Granule rows ping-pong by particle parity (a workgroup that holds K_i knows every
+// reducer has read the partials of row i; one that publishes partials of row i + 2 knows everyone has read K_i).
+// The grid must be resident at once (the launcher checks); a wave that polls `spin_limit` times without progress
+// gives up: *fail is set (the step's loss becomes NaN, k_svgd_loss), every workgroup returns -- the grid always drains.
+struct SvgdGsResArgs {
+  float *all;              // (M, D) particle matrix, updated in place
+  float *adam_m, *adam_v;  // (M, D)
+  const float *grad;       // (M, D)
+  long long D;
+  int M;
+  float lr_t, gamma;
+  int nblk;
+  unsigned *epoch;             // [1] tags <= *epoch are stale; advanced by M per sweep (workgroup 0)
+  unsigned long long *pgran;   // (2, nblk, 64, 2) granules {tag, low half} {tag, high half} of the partials
+  unsigned long long *kgran;   // (2, 64, 2) granules of the kernel row
+  int *fail;
+  int spin_limit;
+};
+
+static inline size_t pyz_svgd_gs_res_lds_bytes() { return pyz_svgd_gs_lds_bytes() + 64; }   // + the row sum of K, the give-up flag
+
+typedef __attribute__((address_space(1))) unsigned long long pyz_gs_gu64;
+__device__ __forceinline__ void pyz_gs_store_f64(unsigned long long *g, const unsigned tag, const double v) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v), t = (unsigned long long)tag << 32;
+  __hip_atomic_store((pyz_gs_gu64 *)g, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((pyz_gs_gu64 *)(g + 1), t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pyz_gs_load(const unsigned long long *g) {
+  return __hip_atomic_load((pyz_gs_gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double pyz_gs_join(const unsigned long long lo, const unsigned long long hi) {
+  return __builtin_bit_cast(double, ((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull));
+}
+
+#ifndef PYZ_GS_POLL_SLEEP
+#define PYZ_GS_POLL_SLEEP 2
+#endif
+__global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
+  extern __shared__ double gs_lds[];
+  double *red = gs_lds;                  // [64][PYZ_GS_PAD]
+  double *ps4 = red + 64 * PYZ_GS_PAD;   // [4][64]
+  double *sd = ps4 + 8 * 64;             // [64]
+  int *gave_up = reinterpret_cast<int *>(sd + 66);
+  const int tid = threadIdx.x, M = g.M, b = blockIdx.x, w = pyz_wave_id(), lane = tid & 63;
+  const long long D = g.D, base = (long long)b * (256 * PYZ_GS_E);
+  const int pj = tid & 63, pq = tid >> 6;
+  if (tid == 0) *gave_up = 0;
+  const unsigned epoch0 = *g.epoch;   // (left by the previous sweep's launch)
+  if (b >= g.nblk) {
+    // ---- a reducer workgroup (no elements of its own): columns 8 r .. 8 r + 7 of every row's squared distances, one wave
+    if (w != 0) return;
+    const int r = b - g.nblk, c = lane >> 3, sl = lane & 7, j = 8 * r + c;
+    for (int inext = 0; inext < M; ++inext) {
+      const unsigned tagn = epoch0 + 1u + (unsigned)inext;
+      const unsigned long long *pp = g.pgran + ((long long)(inext & 1) * g.nblk * 64 + min(j, M - 1)) * 2;
+      // the nblk partials of d_{inext,j}: eight stride-8 slices in block order (the lanes of a column), combined as
+      // k_svgd_gs combines them.  Two batches of sixteen blocks: every load of a batch is issued before the first tag is
+      // looked at (a test per load makes them dependent round trips); blocks past the end repeat the last one.  (One batch of
+      // thirty-two and polls without the sleep: 4 000 cycles per particle SLOWER -- the polls of 216 workgroups get in the
+      // way of the stores they wait for.)
+      double sum = 0.0;
+      bool lost = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned long long lo[16], hi[16];
+        for (int spins = 0;;) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const unsigned long long *p = pp + (long long)min(sl + 8 * (16 * h + u), g.nblk - 1) * 128;
+            lo[u] = pyz_gs_load(p);
+            hi[u] = pyz_gs_load(p + 1);
+          }
+          unsigned bad = 0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) bad |= ((unsigned)(lo[u] >> 32) ^ tagn) | ((unsigned)(hi[u] >> 32) ^ tagn);
+          if (__all(bad == 0)) break;
+          if (++spins > g.spin_limit) {   // (wave-uniform)
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lost) break;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += sl + 8 * (16 * h + u) < g.nblk ? pyz_gs_join(lo[u], hi[u]) : 0.0;
+      }
+      if (lost) {   // the compute workgroups never showed up: they give up on their own polls
+        if (lane == 0) *g.fail = 1;
+        return;
+      }
+      const int l0 = lane & ~7;
+      const double s0 = __shfl(sum, l0, 64), s1 = __shfl(sum, l0 + 1, 64), s2 = __shfl(sum, l0 + 2, 64), s3 = __shfl(sum, l0 + 3, 64);
+      const double s4 = __shfl(sum, l0 + 4, 64), s5 = __shfl(sum, l0 + 5, 64), s6 = __shfl(sum, l0 + 6, 64), s7 = __shfl(sum, l0 + 7, 64);
+      if (sl == 0 && j < M) {
+        const double dsq = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        pyz_gs_store_f64(g.kgran + ((long long)(inext & 1) * 64 + j) * 2, tagn, exp(-(double)g.gamma * dsq));
+      }
+    }
+    return;
+  }
+  long long e[PYZ_GS_E];
+  bool in[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) {
+    e[q] = base + PYZ_GS_E * tid + q;
+    in[q] = e[q] < D;
+    e[q] = in[q] ? e[q] : D - 1;
+  }
+  const bool whole = base + (long long)PYZ_GS_E * 64 * (w + 1) <= D;  // all elements of this WAVE exist (scalar)
+  // the workgroup's elements of every row, once
+  float x[64][PYZ_GS_E];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (whole) {
+      const pyz_gs_vec v = *reinterpret_cast<const pyz_gs_vec *>(g.all + (long long)min(j, M - 1) * D + e[0]);
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = v[q];
+    } else {
+      const float *row = g.all + (long long)min(j, M - 1) * D;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = row[e[q]];
+    }
+  }
+  float xnext[PYZ_GS_E], xi[PYZ_GS_E], gi[PYZ_GS_E], am[PYZ_GS_E], av[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) {
+    xnext[q] = x[0][q];
+    xi[q] = gi[q] = am[q] = av[q] = 0.0f;
+  }
+  __syncthreads();   // gave_up is initialised
+#ifdef PYZ_STAMPS
+  unsigned long long lap[16] = {0};
+  PYZ_LAP(lap, 8);
+  lap[8] = 0;
+#else
+  unsigned long long *lap = nullptr;
+#endif
+  for (int i = -1; i < M; ++i) {
+    const int inext = i + 1;
+    PYZ_LAP(lap, 5);
+    // -- partial squared distances of row i + 1 against every row as it stands (row i is about to change: its term is
+    //    recomputed below); float64 differences and squares (SVGD.py:198-201)
+    if (inext < M) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < PYZ_GS_E; ++q) {
+          const double df = in[q] ? (double)xnext[q] - (double)x[j][q] : 0.0;
+          a = fma(df, df, a);
+        }
+        red[j * PYZ_GS_PAD + tid] = a;
+      }
+    }
+    PYZ_LAP(lap, 0);
+    if (i >= 0) {
+      // -- the kernel row of particle i: the first wave polls the reducers' granules
+      const unsigned tag = epoch0 + 1u + (unsigned)i;
+      if (w == 0) {
+        const unsigned long long *kg = g.kgran + ((long long)(i & 1) * 64 + lane) * 2;
+        unsigned long long lo = 0, hi = 0;
+        for (int spins = 0;;) {
+          lo = pyz_gs_load(kg);
+          hi = pyz_gs_load(kg + 1);
+          const bool ok = lane >= M || ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag);
+          if (__all(ok)) break;
+          if (++spins > g.spin_limit) {   // (wave-uniform)
+            *gave_up = 1;
+            *g.fail = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(PYZ_GS_POLL_SLEEP);
+        }
+        const double kv = lane < M ? pyz_gs_join(lo, hi) : 0.0;
+        sd[lane] = kv;
+        float ks = 0.0f;                 // sum_j (float) K_ij, j ascending (+0.0f past M): once per workgroup
+        const float kf = (float)kv;
+        for (int j = 0; j < 64; ++j) ks += __shfl(kf, j, 64);
+        if (lane == 0) sd[64] = (double)ks;
+      }
+      pyz_lds_barrier();
+      if (*gave_up) {   // (uniform) the others never showed up: not resident together, or one of them gave up
+        if (b == 0 && tid == 0) *g.epoch = epoch0 + (unsigned)M;
+        return;
+      }
+      PYZ_LAP(lap, 1);
+      const float ksum = (float)sd[64];
+      double rep[PYZ_GS_E];
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const double kdj = sd[j];
+#pragma unroll
+        for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = fma(kdj, (double)xi[q] - (double)x[j][q], rep[q]);
+      }
+      double acc_i = 0.0;
+      float xn[PYZ_GS_E];
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) {
+        float m = am[q], v = av[q];
+        pyz_svgd_gs_adam(ksum, gi[q], rep[q], g.gamma, M, xi[q], g.lr_t, m, v, xn[q]);
+        if (in[q]) {
+          const long long o = (long long)i * D + e[q];
+          g.adam_m[o] = m;
+          g.adam_v[o] = v;
+          g.all[o] = xn[q];
+          const double df = (double)xnext[q] - (double)xn[q];
+          acc_i = fma(df, df, acc_i);
+        }
+      }
+      if (inext < M) red[i * PYZ_GS_PAD + tid] = acc_i;   // the updated row i (same thread, after its first write)
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) xi[q] = xn[q];   // (kept for the register copy, patched behind the publish)
+    }
+    if (inext >= M) break;
+    PYZ_LAP(lap, 2);
+    pyz_lds_barrier();
+    {
+      const double *rp = red + pj * PYZ_GS_PAD + 64 * pq;
+      double s = 0.0;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += 16) {   // (the reads of a batch in flight together; the sum stays in order)
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = rp[t0 + t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += v[t];
+      }
+      ps4[pq * 64 + pj] = s;
+    }
+    pyz_lds_barrier();
+    PYZ_LAP(lap, 3);
+    const unsigned tagn = epoch0 + 1u + (unsigned)inext;
+    if (w == 0) {   // this block's partials of row i + 1
+      const double tot = lane < M ? (ps4[lane] + ps4[64 + lane]) + (ps4[128 + lane] + ps4[192 + lane]) : 0.0;
+      pyz_gs_store_f64(g.pgran + (((long long)(inext & 1) * g.nblk + b) * 64 + lane) * 2, tagn, tot);
+    }
+    // the register copy of row i: i is uniform, so this is a scalar jump into one of 64 three-move cases (192 selects --
+    // with part of x living in accumulation registers, three instructions each -- took 4 000 cycles per particle)
+#define PYZ_GS_PATCH(J) case J: _Pragma("unroll") for (int q = 0; q < PYZ_GS_E; ++q) x[J][q] = xi[q]; break;
+#define PYZ_GS_PATCH8(J) PYZ_GS_PATCH(J) PYZ_GS_PATCH(J + 1) PYZ_GS_PATCH(J + 2) PYZ_GS_PATCH(J + 3) PYZ_GS_PATCH(J + 4) PYZ_GS_PATCH(J + 5) PYZ_GS_PATCH(J + 6) PYZ_GS_PATCH(J + 7)
+    switch (i) {
+      PYZ_GS_PATCH8(0) PYZ_GS_PATCH8(8) PYZ_GS_PATCH8(16) PYZ_GS_PATCH8(24) PYZ_GS_PATCH8(32) PYZ_GS_PATCH8(40) PYZ_GS_PATCH8(48) PYZ_GS_PATCH8(56)
+      default: break;
+    }
+#undef PYZ_GS_PATCH8
+#undef PYZ_GS_PATCH
+    PYZ_LAP(lap, 4);
+    // -- the next particle's operands (rows >= i + 1 are still the values the sweep started with)
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      const long long o = (long long)inext * D + e[q];
+      xi[q] = xnext[q];
+      gi[q] = g.grad[o];
+      am[q] = g.adam_m[o];
+      av[q] = g.adam_v[o];
+      xnext[q] = inext + 1 < M ? g.all[(long long)(inext + 1) * D + e[q]] : 0.0f;
+    }
+  }
+  if (b == 0 && tid == 0) *g.epoch = epoch0 + (unsigned)M;
+#ifdef PYZ_STAMPS
+  if (lane == 0 && b < PYZ_STAMP_BLOCKS)
+    for (int k = 0; k < 8; ++k) pyz_dbg_buf[3][b][w][k][0] = lap[k];
+#endif
+}
+
+// d_loss[0] = sum_i loss_i / M   (SVGD.py:125); `fail` (the resident sweep's workgroups did not meet): NaN, counted
+__global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out, int *fail, int *nonfinite) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.0f;
     for (int i = 0; i < n_local; ++i) s += loss[i] / (float)M;
+    if (fail && *fail) {
+      s = __builtin_nanf("");
+      *fail = 0;
+      atomicAdd(nonfinite, 1);
+    }
     out[0] = s;
   }
 }

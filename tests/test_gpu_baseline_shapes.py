@@ -233,13 +233,14 @@ def test_c4_bbb_full_shape(eng, init):
 from svgd_checks import lr_t as _lr_t, strict_particle_check as _strict_particle_check  # noqa: E402
 
 
-@pytest.mark.parametrize("sweep,path", [("gauss_seidel", "fused"), ("gauss_seidel", "rows"), ("jacobi", "gram"),
+@pytest.mark.parametrize("sweep,path", [("gauss_seidel", "resident"), ("gauss_seidel", "fused"), ("gauss_seidel", "rows"), ("jacobi", "gram"),
                                         ("jacobi", "pairwise"), ("jacobi", "rows")])
 def test_c5_svgd_64_particles_coupled(eng, monkeypatch, sweep, path):
     """M = 64 on 64 -> 40 -> 24 -> 10 (D = 3 834: five k_svgd_gs workgroups with a ragged last one, the prefetch
     window of 32 rows wraps, all ten 16 x 16 blocks of the Gram kernel) with K_ij ~ 0.2: two steps against the
     oracle, every kernel path; under the Jacobi sweep rows [32, 64) as a shard == the same rows of the whole."""
-    monkeypatch.setenv("PYZ_SVGD_GS_FUSED", "1" if path == "fused" else "0")
+    monkeypatch.setenv("PYZ_SVGD_GS_FUSED", "1" if path in ("fused", "resident") else "0")
+    monkeypatch.setenv("PYZ_SVGD_GS_RESIDENT", "1" if path == "resident" else "0")
     monkeypatch.setenv("PYZ_SVGD_GRAM", "1" if path == "gram" else "0")
     monkeypatch.setenv("PYZ_SVGD_TILES", "0" if (sweep == "jacobi" and path == "rows") else "1")
     spec, n, M, lr = WIDE3, 130, 64, 1e-3
@@ -274,12 +275,14 @@ def test_c5_svgd_64_particles_coupled(eng, monkeypatch, sweep, path):
     plan.close()
 
 
-@pytest.mark.parametrize("sweep", ["gauss_seidel", "jacobi"])
-def test_c5_svgd_full_shape(eng, sweep):
+@pytest.mark.parametrize("sweep", ["gauss_seidel", "gauss_seidel_per_launch", "jacobi"])
+def test_c5_svgd_full_shape(eng, sweep, monkeypatch):
     """One pyz_svgd_step at the real C5 shape: 64 particles of 784 -> 200 -> 10 (D = 159 010), batch 1024.
     The particles sit 1e-3 around a Glorot point (|x_i - x_j|^2 ~ 0.3, K_ij ~ 0.7) so that the kernel matrix and
     the repulsion matter at this size; with the reference's N(0, 1) start K underflows to exactly I (second
     case below: phi_i = g_i / M)."""
+    monkeypatch.setenv("PYZ_SVGD_GS_RESIDENT", "0" if sweep == "gauss_seidel_per_launch" else "1")
+    sweep = sweep.replace("_per_launch", "")
     spec, M, B, lr = MNIST, 64, 1024, 0.01
     D = spec.n_params
     x, y = synth.mnist_like(2048)

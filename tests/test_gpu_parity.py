@@ -475,7 +475,7 @@ def test_svgd_step_matches_oracle(eng, sweep):
     plan.close()
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 1, 0])
 def test_svgd_gauss_seidel_paths(eng, monkeypatch, fused):
     """The reference-order sweep as one launch per particle (k_svgd_gs: the matrix in registers, partial
     distances handed from launch to launch) and as the two per-row kernels: both against the oracle, on a
@@ -484,7 +484,8 @@ def test_svgd_gauss_seidel_paths(eng, monkeypatch, fused):
     Adam's first steps move every element by ~lr * sign(phi): where phi is ~0 (dead units) float32 and float64
     may disagree on the sign, so the update direction is checked through Adam's m and v (linear / quadratic in
     phi), and the particles on all but a handful of elements."""
-    monkeypatch.setenv("PYZ_SVGD_GS_FUSED", str(fused))
+    monkeypatch.setenv("PYZ_SVGD_GS_FUSED", str(min(fused, 1)))
+    monkeypatch.setenv("PYZ_SVGD_GS_RESIDENT", "1" if fused == 2 else "0")     # 2: the whole sweep as one resident launch
     spec, n = SPECS["wide3"]
     x, y, _ = make(spec, n, seed=57)
     D = spec.n_params
