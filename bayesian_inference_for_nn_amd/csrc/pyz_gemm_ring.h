@@ -125,13 +125,17 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
   const StepCtl ctl = pyz_ctl_first(g.ctl, g.init, g.init_on);
   const int batch = ctl.batch;
   const int K = g.K, N = g.N, P = g.n_part;
-  const int row_tiles = (g.grid_rows + 31) >> 5;
-  const int n_tiles = row_tiles * P;
+  if (g.gate && g.gate->n % g.gate_mod == 0) return;      // (uniform) a gated launch on a step it skips
+  const int row_tiles = (g.grid_rows + 31) >> 5, n_cg = g.n_cgrp;
+  const int n_tiles = row_tiles * P * n_cg;
   if ((int)blockIdx.x >= n_tiles) return;                 // padding of the launch
   // particle-major tile ids: an XCD's contiguous range is (part of) one particle's row blocks, its L2 holds that particle's
   // weights.  (Blocks of 2 / 4 / 8 particles x fewer row blocks per XCD -- every input line then asked for by several
   // workgroups of the XCD -- measured the same: 39.3 - 39.7 us at 8 particles.)  Placement only changes speed.
-  const int tile = pyz_xcd_remap(blockIdx.x, n_tiles);
+  // A layer wider than the 200 columns a workgroup takes is cut into column groups: the groups of a row block are
+  // neighbours in the tile order (same XCD: the block's input rows come out of its L2 for all but the first).
+  const int tile_all = pyz_xcd_remap(blockIdx.x, n_tiles);
+  const int tile = tile_all / n_cg, cgp = tile_all - tile * n_cg, col0 = cgp * g.cgrp_w;
   const int p = tile / row_tiles, m0 = (tile - p * row_tiles) * 32;
   if (m0 >= batch) return;                                // uniform
   const bool moves = NW == 4 || w >= 4, computes = NW == 4 || w < 4;   // roles (scalar)
@@ -165,7 +169,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
     if (id < NI && moves) {
       if (id1 < B_INSTR) {
         const int tt = 64 * id1 + l, kk = tt / PR, c4 = tt - kk * PR;
-        voffB[u] = kk < BK ? (unsigned)((BK * sub + kk) * N * 4 + c4 * 16) : OOB;
+        voffB[u] = kk < BK ? (unsigned)(((BK * sub + kk) * N + col0) * 4 + c4 * 16) : OOB;
       } else {
         const int row = 16 * (id1 - B_INSTR) + (l >> 2);
         koffA[u] = BK * sub + 4 * (l & 3);
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     const int col = 16 * (ct_first + ct) + c16;
-    bias[ct] = wl[(long long)K * N + min(col, N - 1)];
+    bias[ct] = wl[(long long)K * N + min(col0 + col, N - 1)];
   }
   f32x4 acc[CT];
 #pragma unroll
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
   // ---- The pipeline.  Slab s lives in ring slot s % 4.  Barrier B_s makes slab s readable (every moving wave has waited for
   //      its share of it) and tells the moving waves that nobody reads slab s - 2 any more.  A computing wave meets B_{s+1}
   //      in the MIDDLE of slab s; behind it the moving waves request slab s + 3 into the slot of slab s - 1.
-  const bool copies = g.gather_out != nullptr && moves && wq < 2;       // the two waves that store the batch copy (scalar)
+  const bool copies = g.gather_out != nullptr && moves && wq < 2 && cgp == 0;   // the two waves that store the batch copy (scalar)
 #ifdef PYZ_STAMPS   // diagnostic build: cycles of this wave per phase, summed over the slabs
   unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = 0;
 #define PYZ_RING_PHASE(i)                                         \
@@ -368,7 +372,8 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int mm = m0 + 16 * rh + 4 * q + r;
-      if (mm < batch && col < N) pyz_st(op + (long long)mm * N + col, pyz_act(acc[ct][r] + bias[ct], act), wt);
+      if (mm < batch && col < g.cgrp_w && col0 + col < N)
+        pyz_st(op + (long long)mm * N + col0 + col, pyz_act(acc[ct][r] + bias[ct], act), wt);
     }
   }
 }
@@ -379,13 +384,18 @@ static inline int pyz_fwd_ring_variant(const DenseArgs &g, int grid_batch, int P
   static const int on = pyz_env_int("PYZ_FWD_RING", 1);
   static const int min_wg = pyz_env_int("PYZ_FWD_RING_MINWG", 192);
   static const int max_wg = pyz_env_int("PYZ_FWD_RING_MAXWG", 1024);
-  if (!on || g.gate) return 0;
-  const long long wgs = (long long)((grid_batch + 31) / 32) * P;
+  if (!on) return 0;
+  const int n_cg = g.N > 200 ? (g.N + 199) / 200 : 1;      // column groups of 200
+  const long long wgs = (long long)((grid_batch + 31) / 32) * P * n_cg;
   if (wgs < min_wg || wgs > max_wg) return 0;
   if (g.K % 4 || g.N % 4 || g.lda % 4 || g.w_off % 4 || (P > 1 && g.in_pstride % 4)) return 0;
   if ((reinterpret_cast<uintptr_t>(g.in) & 15) || (g.gather_out && (reinterpret_cast<uintptr_t>(g.gather_out) & 15))) return 0;
   if ((reinterpret_cast<uintptr_t>(g.theta) & 3)) return 0;
   if (g.N > 192 && g.N <= 200) return 1;   // <204, 13>
+  // ... per column group of 200 (784 -> 400 -> 400: the 6 000-row validation forward of C4).  Opt-in (PYZ_FWD_RING_WIDE=1, read
+  // per call): measured equal to k_dense_fwd there (65.6 + 39.6 against 68.3 + 36.6 us) -- 376 workgroups of 32 rows x 200
+  // columns sit two to a CU on 120 CUs and one on the rest, the launch lasts as long as the pairs.
+  if (g.N > 200 && g.N % 200 == 0 && g.N <= 1600 && pyz_env_int("PYZ_FWD_RING_WIDE", 0)) return 1;
   return 0;
 }
 
@@ -394,7 +404,9 @@ static inline void pyz_launch_fwd_ring_as(const DenseArgs &g, int grid_batch, in
   DenseArgs a = g;
   a.n_part = P;
   a.grid_rows = grid_batch;
-  const long long wgs = (long long)((grid_batch + 31) / 32) * P;
+  a.n_cgrp = g.N > 200 ? (g.N + 199) / 200 : 1;
+  a.cgrp_w = g.N > 200 ? 200 : g.N;
+  const long long wgs = (long long)((grid_batch + 31) / 32) * P * a.n_cgrp;
   PYZ_LAUNCH((k_dense_fwd_ring<NL, NCT, SUB, NW>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * NW), 0, st, a);
 }
 
@@ -405,7 +417,7 @@ static inline bool pyz_launch_fwd_ring(const DenseArgs &g, int grid_batch, int P
       // CU) while the launch has no second workgroup per CU anyway -- 8 particles: 36.9 against 39.3 us -- else one (61 KB,
       // two per CU: 16 particles 62.0 against 70.5 us).  PYZ_FWD_RING_SUB / PYZ_FWD_RING_WAVES force a variant (measurements).
       static const int sub_env = pyz_env_int("PYZ_FWD_RING_SUB", 0), nw = pyz_env_int("PYZ_FWD_RING_WAVES", 8);
-      const long long wgs = (long long)((grid_batch + 31) / 32) * P;
+      const long long wgs = (long long)((grid_batch + 31) / 32) * P * (g.N > 200 ? (g.N + 199) / 200 : 1);
       const int sub = sub_env ? sub_env : (4 * wgs <= 5 * (long long)pyz_cu_count() ? 2 : 1);
       if (nw == 4 && sub == 2) pyz_launch_fwd_ring_as<204, 13, 2, 4>(g, grid_batch, P, st);
       else if (nw == 4) pyz_launch_fwd_ring_as<204, 13, 1, 4>(g, grid_batch, P, st);

@@ -83,3 +83,37 @@ def test_ring_forward_feeds_the_gradient_pass(eng, P, batch):
         close(loss[p:p + 1], [rl], what=f"loss {p}")
         close(grad[p], rg, what=f"gradient {p}")
     plan.close()
+
+
+C4 = o_mlp.MLPSpec((784, 400, 400, 10), ("relu", "relu", "softmax"), "scce")
+
+
+@pytest.mark.parametrize("P,rows,gather", [(1, 6000, False), (1, 5989, True), (3, 2048, True)])
+def test_ring_forward_on_column_groups(eng, P, rows, gather, monkeypatch):
+    """Layers wider than the 200 columns a workgroup takes (BASELINE configs[3], 784 -> 400 -> 400 -> 10: the 6 000-row
+    validation forward of BBB.py:203-209) are cut into column groups of 200; both hidden layers through the ring, ragged
+    row counts, gathered rows, several particles -- against the oracle (to
+    float32 summation order)."""
+    monkeypatch.setenv("PYZ_FWD_RING_WIDE", "1")     # (opt-in: no faster than k_dense_fwd at this shape, pyz_gemm_ring.h)
+    n = 6000
+    x, y = synth.mnist_like(n)
+    rng = np.random.default_rng(7 + rows)
+    base = synth.glorot_uniform(C4.dims)
+    parts = (base[None, :] + 0.02 * rng.normal(size=(P, C4.n_params))).astype(np.float32)
+    plan = eng.MLPPlan(eng.MLPSpec(C4.dims, C4.acts, C4.loss), max_batch=n, max_particles=P)
+    idx = rng.permutation(n)[:rows].astype(np.int32) if gather else None
+    with eng.KernelProbe(16) as kp:
+        out = plan.forward(dev(parts), dev(x), batch=rows, row_idx=dev(idx, torch.int32) if gather else None)
+    ring = [nm for nm, _ in kp.launches if nm.startswith("k_dense_fwd_ring")]
+    assert len(ring) == 2, kp.launches
+    xs = x[idx] if gather else x[:rows]
+    for p in range(P):
+        ref = o_mlp.predict(parts[p], xs, C4)
+        close(out[p], ref, what=f"particle {p}")
+    if P > 1:      # and as the first kernels of a gradient pass (the batch copy is left by the first column group only)
+        loss, grad = plan.loss_grad(dev(parts), dev(x), dev(y, torch.int32), batch=rows, row_idx=dev(idx, torch.int32))
+        for p in range(P):
+            rl, rg, _ = o_mlp.loss_and_grad(parts[p], x[idx], y[idx], C4)
+            close(loss[p:p + 1], [rl], what=f"loss {p}")
+            close(grad[p], rg, rel=2e-4, what=f"gradient {p}")
+    plan.close()
