@@ -36,6 +36,8 @@ struct Extra {  // lazily sized buffers kept beside the plan
   size_t hm_cap = 0;
   void *hm_res_buf = nullptr;  // k_hmc_resident: per-chain epochs and the granule rows
   size_t hm_res_cap = 0;
+  void *fwd_part = nullptr;    // k_dense_fwd_ring with a split reduction: (k_split, max_batch, width) raw partial sums
+  size_t fwd_part_cap = 0;
   void *gs_res_buf = nullptr;  // k_svgd_gs_resident: epoch, fail flag, granules of the partials and of the kernel row
   size_t gs_res_cap = 0;
   hipGraph_t hm_graph = nullptr;  // the launch sequence of one sliced HMC proposal
@@ -254,11 +256,18 @@ inline bool can_fuse(const pyz_mlp *m) { return m->dims[m->L] <= 32; }
 
 void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
                  const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_delta, hipStream_t st,
-                 const StepCtl *gate = nullptr, int gate_mod = 0) {
+                 const StepCtl *gate = nullptr, int gate_mod = 0, int k_split = 0) {
   const int l = m->L - 1;
   HeadArgs g{};
   g.gate = gate;
   g.gate_mod = gate_mod;
+  if (k_split > 1) {   // the hidden layer arrives as the partial sums of a split-reduction forward (ksplit_forward_ok)
+    g.hparts = static_cast<const float *>(full(m)->x.fwd_part);
+    g.n_hparts = k_split;
+    g.hpart_stride = (long long)m->max_batch * m->dims[l];
+    g.bias_prev = theta + m->w_off[l - 1] + (long long)m->dims[l - 1] * m->dims[l];
+    g.h_store = m->act[l - 1];
+  }
   g.K = m->dims[l];
   g.N = m->dims[l + 1];
   if (l == 0) {
@@ -426,14 +435,44 @@ PrepArgs prep_args(pyz_mlp *m, const float *x, const int32_t *row_idx, int grid_
 // forward + loss (+ backward into `grad` when upd.mode == NONE and grad given, or the fused update).
 // ahead_slot >= 0 (chained runs): this step's rows already stand in batch_buf(ahead_slot), and upd.prep says where the
 // weight-gradient launch assembles the next step's.
+// split-reduction forward (k_dense_fwd_ring, k_split) + partial-summing head for this launch?  Returns the split (0: no).
+int ksplit_for(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *xc, int grid_batch, const StepCtl *ctl) {
+  // Opt-in (read when a run's graph is captured): measured SLOWER at C2 -- 27.5 us per step with 8 ranges, 30.3 with 4, against
+  // 24.6 (the forward ~10.7 us against 8.5: seven slabs do not amortise the ring's prologue and the 6.5 MB of partial sums;
+  // the head 6.6 against 4.6 us: 32 loads per lane instead of 4) -- profiles/r03_ksplit/.
+  const int ks_env = pyz_env_int("PYZ_FWD_KSPLIT", 0);
+  if (ks_env < 2 || ks_env > 8 || m->L != 2 || P != 1) return 0;
+  const int UT = m->dims[1] <= 64 ? 1 : m->dims[1] <= 256 ? 4 : 0, NPc = m->dims[2];
+  if (!UT || NPc > 16 || !pyz_env_int("PYZ_HEAD_ROWS", 1)) return 0;          // the head must be k_head_rows
+  DenseArgs g = forward_args(m, 0, theta, theta_ps, xc, nullptr, ctl, nullptr);
+  if (!pyz_fwd_ring_ksplit_ok(g, grid_batch, P)) return 0;
+  if ((long long)((grid_batch + 31) / 32) * ks_env > 2 * pyz_cu_count()) return 0;   // (already enough row blocks)
+  // (the buffer of partial sums is allocated with the plan: this runs inside stream capture, where nothing may be allocated)
+  const size_t need = sizeof(float) * (size_t)ks_env * m->max_batch * m->dims[1];
+  if (!full(m)->x.fwd_part || full(m)->x.fwd_part_cap < need) return 0;
+  return ks_env;
+}
+
 void launch_loss_backward(pyz_mlp *m, const float *theta, long long theta_ps, int P, const float *x, const void *y,
                           const int32_t *row_idx, int grid_batch, const StepCtl *ctl, bool want_grad, WgradArgs &upd,
                           hipStream_t st, int ahead_slot = -1) {
   if (can_fuse(m)) {
     if (ahead_slot >= 0) {
       const float *xc = batch_buf(m, ahead_slot);
-      launch_forward(m, theta, theta_ps, P, xc, nullptr, grid_batch, ctl, st, nullptr, m->L - 1);
-      launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st);   // (labels go through row_idx)
+      // one hidden layer of <= 200 units, one chain: the forward with its reduction split over PYZ_FWD_KSPLIT workgroups per
+      // row block, the head adds the partial sums (see pyz_gemm_ring.h)
+      const int ks = ksplit_for(m, theta, theta_ps, P, xc, grid_batch, ctl);
+      if (ks > 1) {
+        DenseArgs g = forward_args(m, 0, theta, theta_ps, xc, nullptr, ctl, nullptr);
+        g.wt = pyz_wt_for(P);
+        g.k_split = ks;
+        g.part_out = static_cast<float *>(full(m)->x.fwd_part);
+        g.part_stride = (long long)m->max_batch * g.N;
+        pyz_launch_fwd_ring_ksplit(g, grid_batch, st);
+      } else {
+        launch_forward(m, theta, theta_ps, P, xc, nullptr, grid_batch, ctl, st, nullptr, m->L - 1);
+      }
+      launch_head(m, theta, theta_ps, P, x, y, row_idx, grid_batch, ctl, want_grad, st, nullptr, 0, ks);   // (labels go through row_idx)
       launch_bwd_data_hidden(m, theta, theta_ps, P, grid_batch, ctl, st);
       launch_wgrad_all(m, P, x, row_idx, grid_batch, ctl, upd, st, xc);
       return;
@@ -547,6 +586,11 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     const int rc = need_part(m, (size_t)max_particles * max_batch + 8);  // up to one loss partial per row (k_head_rows)
     if (rc != PYZ_OK) return fail(rc);
   }
+  // a single chain's one hidden layer of <= 200 units (C2): room for the partial sums of the split-reduction forward
+  if (m->L == 2 && m->dims[1] > 192 && m->dims[1] <= 200) {
+    const int rc = ensure_bytes(&m->x.fwd_part, &m->x.fwd_part_cap, sizeof(float) * (size_t)8 * max_batch * m->dims[1], m);
+    if (rc != PYZ_OK) return fail(rc);
+  }
   // kernels with more than 64 KB of dynamic LDS: the allowance is a per-device attribute of the function, set here for the
   // device this plan lives on (one process may drive several devices, each through plans of its own)
   {
@@ -577,7 +621,7 @@ int pyz_mlp_destroy(pyz_mlp *mm) {
     if (m->act[l]) (void)hipFree(m->act[l]);
     if (m->delta[l]) (void)hipFree(m->delta[l]);
   }
-  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->x.hm_res_buf, m->x.gs_res_buf, m->nonfinite};
+  void *ptrs[] = {m->grad, m->grad2, m->qsave, m->part, m->x.part2, m->scal, m->ctl, m->tab_bs, m->xb, m->x.hm_buf, m->x.hm_res_buf, m->x.gs_res_buf, m->x.fwd_part, m->nonfinite};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->x.tab_host) {

@@ -44,6 +44,14 @@ struct HeadArgs {
   int wt;                    // write-through stores for the outputs (pyz_st)
   const StepCtl *gate;       // when set: nothing happens on steps with gate->n % gate_mod == 0 (see DenseArgs)
   int gate_mod;
+  // k_head_rows behind a split-reduction forward (k_dense_fwd_ring, k_split): the hidden layer arrives as n_hparts <= 8 raw
+  // partial sums (hparts + s * hpart_stride + row * K + unit); the head adds them in split order, then the hidden layer's
+  // bias (bias_prev[unit]) and activation (act_prev), and stores the row of activations to h_store for the weight gradients
+  const float *hparts;
+  int n_hparts;
+  long long hpart_stride;
+  const float *bias_prev;
+  float *h_store;
 };
 
 // lanes 8q..8q+7 of a wave cooperate on one row: reductions over the 8-lane group
@@ -315,8 +323,36 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
   // into whole-vector copies).
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
   float hv[UT], z[NP];
+  if (g.n_hparts > 0) {
+    // the hidden layer as raw partial sums of a split reduction: eight loads per unit in flight together (splits past
+    // n_hparts are out of range: zero), summed in split order; then bias and activation; the row goes to h_store
+    const float *pp = g.hparts + (long long)m * K;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pp), 0,
+        (int)(((long long)(g.n_hparts - 1) * g.hpart_stride + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.bias_prev), 0, K * 4, 0x00020000);
+    constexpr unsigned OOBH = 0x7FFFFF00u;
+    float pv[UT][8], bv[UT];
 #pragma unroll
-  for (int t = 0; t < UT; ++t) hv[t] = pyz_buf_load(rh, 4u * (unsigned)(l + 64 * t), 0u);
+    for (int t = 0; t < UT; ++t) {
+      const int u = l + 64 * t;
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp)
+        pv[t][sp] = pyz_buf_load(rp, (u < K && sp < g.n_hparts) ? 4u * (unsigned)(sp * g.hpart_stride + u) : OOBH, 0u);
+      bv[t] = pyz_buf_load(rb, 4u * (unsigned)u, 0u);
+    }
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      float a = pv[t][0];
+#pragma unroll
+      for (int sp = 1; sp < 8; ++sp) a += pv[t][sp];
+      hv[t] = pyz_act(a + bv[t], g.act_prev);
+      const int u = l + 64 * t;
+      if (u < K) pyz_st(g.h_store + (long long)m * K + u, hv[t], g.wt);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < UT; ++t) hv[t] = pyz_buf_load(rh, 4u * (unsigned)(l + 64 * t), 0u);
+  }
   if (!PRELOADED) pyz_head_load_w<UT, NP>(g, p, l, W);
   const auto &wv = W.wv;
   const float bias_mine = W.bias_mine;

@@ -51,6 +51,9 @@ struct DenseArgs {
   int rows_cap;               // forward, k_dense_fwd: > 0 = readable rows of a contiguous `in` (see the kernel)
   int n_part, grid_rows;      // forward, k_dense_fwd_ring (1-D grid): particles and rows of the launch
   int n_cgrp, cgrp_w;         // forward, k_dense_fwd_ring: column groups per row block (layers wider than one workgroup's 200 columns) and their width
+  int k_split;                // forward, k_dense_fwd_ring: > 1 = the reduction cut into k_split ranges of slabs, one workgroup each; raw partial sums
+  float *part_out;            //   (no bias, no activation) go to part_out + split * part_stride + row * N + column: the consumer
+  long long part_stride;      //   (k_head_rows) adds them in split order, then the bias and the activation
   const StepCtl *gate;        // forward (k_dense_fwd): when set, the launch does nothing on steps with gate->n % gate_mod == 0
   int gate_mod;               // (the validation forward of a device-resident BBB run: BBB.py:203 skips every tenth step)
 };

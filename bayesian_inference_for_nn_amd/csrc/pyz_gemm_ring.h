@@ -126,15 +126,19 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
   const int batch = ctl.batch;
   const int K = g.K, N = g.N, P = g.n_part;
   if (g.gate && g.gate->n % g.gate_mod == 0) return;      // (uniform) a gated launch on a step it skips
-  const int row_tiles = (g.grid_rows + 31) >> 5, n_cg = g.n_cgrp;
-  const int n_tiles = row_tiles * P * n_cg;
+  const int row_tiles = (g.grid_rows + 31) >> 5, n_cg = g.n_cgrp, n_ks = g.k_split > 1 ? g.k_split : 1;
+  const int n_tiles_1 = row_tiles * P * n_cg, n_tiles = n_tiles_1 * n_ks;
   if ((int)blockIdx.x >= n_tiles) return;                 // padding of the launch
   // particle-major tile ids: an XCD's contiguous range is (part of) one particle's row blocks, its L2 holds that particle's
   // weights.  (Blocks of 2 / 4 / 8 particles x fewer row blocks per XCD -- every input line then asked for by several
   // workgroups of the XCD -- measured the same: 39.3 - 39.7 us at 8 particles.)  Placement only changes speed.
   // A layer wider than the 200 columns a workgroup takes is cut into column groups: the groups of a row block are
   // neighbours in the tile order (same XCD: the block's input rows come out of its L2 for all but the first).
-  const int tile_all = pyz_xcd_remap(blockIdx.x, n_tiles);
+  // Split reduction (a single chain's launch has too few row blocks to fill the chip): the range of slabs is the SLOW index
+  // of the tile order -- an XCD's contiguous range of tiles is then the row blocks of one range, which share its rows of
+  // [W; b] in that XCD's L2.
+  const int tile_ks = pyz_xcd_remap(blockIdx.x, n_tiles);
+  const int ksp = tile_ks / n_tiles_1, tile_all = tile_ks - ksp * n_tiles_1;
   const int tile = tile_all / n_cg, cgp = tile_all - tile * n_cg, col0 = cgp * g.cgrp_w;
   const int p = tile / row_tiles, m0 = (tile - p * row_tiles) * 32;
   if (m0 >= batch) return;                                // uniform
@@ -181,7 +185,15 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
     }
   }
   const unsigned slabB = (unsigned)(KS * N * 4);          // bytes per slab of B
-  const int ns = (K + KS - 1) / KS;
+  const int ns_all = (K + KS - 1) / KS;
+  const int s_lo = (int)((long long)ns_all * ksp / n_ks), ns = (int)((long long)ns_all * (ksp + 1) / n_ks) - s_lo;   // this workgroup's slabs
+  if (s_lo > 0) {
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      if (voffB[u] != OOB) voffB[u] += (unsigned)s_lo * slabB;
+      if (srcA[u]) srcA[u] += (long long)s_lo * KS;
+    }
+  }
 
   auto issue = [&](const int s) {                         // the DMA of slab s into ring slot s % NBUF
     unsigned char *base = ring + (s & (NBUF - 1)) * SLOT;
@@ -193,7 +205,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (pyz_lds_void *)(base + sub * SUBSLOT + id1 * 1024), 16, (int)voffB[u], 0, 0, 0);
           voffB[u] += slabB;
         } else {
-          const float *src = (KS * s + koffA[u] < K) ? srcA[u] : pyz_zero16;
+          const float *src = (KS * (s_lo + s) + koffA[u] < K) ? srcA[u] : pyz_zero16;
           __builtin_amdgcn_global_load_lds((pyz_glb_void *)src, (pyz_lds_void *)(base + sub * SUBSLOT + id1 * 1024), 16, 0, 0);
           srcA[u] += KS;
         }
@@ -218,7 +230,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
   // ---- The pipeline.  Slab s lives in ring slot s % 4.  Barrier B_s makes slab s readable (every moving wave has waited for
   //      its share of it) and tells the moving waves that nobody reads slab s - 2 any more.  A computing wave meets B_{s+1}
   //      in the MIDDLE of slab s; behind it the moving waves request slab s + 3 into the slot of slab s - 1.
-  const bool copies = g.gather_out != nullptr && moves && wq < 2 && cgp == 0;   // the two waves that store the batch copy (scalar)
+  const bool copies = g.gather_out != nullptr && moves && wq < 2 && cgp == 0 && n_ks == 1;   // the two waves that store the batch copy (scalar)
 #ifdef PYZ_STAMPS   // diagnostic build: cycles of this wave per phase, summed over the slabs
   unsigned long long ph[4] = {0, 0, 0, 0}, ph_t = 0;
 #define PYZ_RING_PHASE(i)                                         \
@@ -258,7 +270,7 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
         for (int sub = 0; sub < SUB; ++sub) {
           f32x4 v;
           asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(src), "n"(sub * SUBSLOT));
-          const int k = KS * s + BK * sub + 4 * pc;
+          const int k = KS * (s_lo + s) + BK * sub + 4 * pc;
           if (m0 + row < batch && k < K) *reinterpret_cast<f32x4 *>(g.gather_out + (long long)(m0 + row) * K + k) = v;
         }
       }
@@ -372,8 +384,10 @@ __global__ void __launch_bounds__(64 * NW) k_dense_fwd_ring(DenseArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int mm = m0 + 16 * rh + 4 * q + r;
-      if (mm < batch && col < g.cgrp_w && col0 + col < N)
-        pyz_st(op + (long long)mm * N + col0 + col, pyz_act(acc[ct][r] + bias[ct], act), wt);
+      if (mm < batch && col < g.cgrp_w && col0 + col < N) {
+        if (n_ks > 1) pyz_st(g.part_out + (long long)ksp * g.part_stride + (long long)mm * N + col0 + col, acc[ct][r], wt);
+        else pyz_st(op + (long long)mm * N + col0 + col, pyz_act(acc[ct][r] + bias[ct], act), wt);
+      }
     }
   }
 }
@@ -408,6 +422,24 @@ static inline void pyz_launch_fwd_ring_as(const DenseArgs &g, int grid_batch, in
   a.cgrp_w = g.N > 200 ? 200 : g.N;
   const long long wgs = (long long)((grid_batch + 31) / 32) * P * a.n_cgrp;
   PYZ_LAUNCH((k_dense_fwd_ring<NL, NCT, SUB, NW>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * NW), 0, st, a);
+}
+
+// the split-reduction form for a single chain's hidden layer of <= 200 units (C2: 1024 x 784 -> 200 is 32 row blocks; cut
+// into k_split ranges of slabs it is 256 workgroups): caller checked the shape (pyz_fwd_ring_ksplit_ok) and set part_out
+static inline bool pyz_fwd_ring_ksplit_ok(const DenseArgs &g, int grid_batch, int P) {
+  if (P != 1 || g.gate || g.row_idx || g.gather_out || g.init_on) return false;
+  if (g.K % 4 || g.N % 4 || g.lda % 4 || g.w_off % 4) return false;
+  if ((reinterpret_cast<uintptr_t>(g.in) & 15) || (reinterpret_cast<uintptr_t>(g.theta) & 3)) return false;
+  return g.N > 192 && g.N <= 200 && g.K >= 16 * 8;
+}
+static inline void pyz_launch_fwd_ring_ksplit(const DenseArgs &g, int grid_batch, hipStream_t st) {
+  DenseArgs a = g;
+  a.n_part = 1;
+  a.grid_rows = grid_batch;
+  a.n_cgrp = 1;
+  a.cgrp_w = g.N;
+  const long long wgs = (long long)((grid_batch + 31) / 32) * g.k_split;
+  PYZ_LAUNCH((k_dense_fwd_ring<204, 13, 1, 8>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * 8), 0, st, a);
 }
 
 static inline bool pyz_launch_fwd_ring(const DenseArgs &g, int grid_batch, int P, hipStream_t st) {

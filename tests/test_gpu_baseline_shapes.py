@@ -109,11 +109,14 @@ def test_c2_sgld_single_steps_full_shape(eng):
     plan.close()
 
 
-@pytest.mark.parametrize("n_steps", [70, 20])
-def test_c2_sgld_graph_run_full_shape(eng, n_steps):
+@pytest.mark.parametrize("n_steps,ksplit", [(70, 0), (20, 0), (70, 8), (20, 4)])
+def test_c2_sgld_graph_run_full_shape(eng, monkeypatch, n_steps, ksplit):
     """pyz_sgld_run(use_graph=1) at the bench shape: 2 944 rows -> batches 1024, 1024, 896 per epoch.  70 steps =
     two replays of the 32-step graph + a 6-step remainder graph; 20 steps = shorter than one chunk (the driver's
-    bench invocation): one graph of exactly 20 steps, its tables carried by the launch that sets the scalars."""
+    bench invocation): one graph of exactly 20 steps, its tables carried by the launch that sets the scalars.
+    ksplit > 0: the opt-in split-reduction forward (k_dense_fwd_ring cut into `ksplit` ranges of slabs per row block, the
+    head adds the partial sums; measured slower at this shape and off by default -- same results to float32 rounding)."""
+    monkeypatch.setenv("PYZ_FWD_KSPLIT", str(ksplit))
     n_rows = 2944
     x, y, theta0 = _c2_data(n_rows)
     D = MNIST.n_params
