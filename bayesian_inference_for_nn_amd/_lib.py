@@ -72,6 +72,7 @@ SIGNATURES = {
     "pyz_upload": (C.c_int, [_p, _p, C.c_size_t, _p]),
     "pyz_download": (C.c_int, [_p, _p, C.c_size_t, _p]),
     "pyz_sync": (C.c_int, [_p]),
+    "pyz_wait_flags": (C.c_int, [_p, C.c_int, C.c_uint64, C.c_int, _p, _p]),
 }
 
 E_NAN = -6

@@ -2048,6 +2048,15 @@ int pyz_download(void *h_dst, const void *d_src, size_t bytes, void *stream) {
   return PYZ_OK;
 }
 
+int pyz_wait_flags(const uint64_t *d_flags, int n, uint64_t value, int spin_limit, int *d_fail, void *stream) {
+  if (!d_flags) return pyz_fail(PYZ_E_INVALID, "null device pointer");
+  if (n < 1 || n > 64) return pyz_fail(PYZ_E_INVALID, "flag count %d outside [1, 64]", n);
+  PYZ_LAUNCH(k_wait_flags, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const unsigned long long *>(d_flags), n,
+             (unsigned long long)value, spin_limit, d_fail);
+  PYZ_LAUNCH_CHECK();
+  return PYZ_OK;
+}
+
 int pyz_sync(void *stream) {
   PYZ_HIP(hipStreamSynchronize(as_stream(stream)));
   return PYZ_OK;

@@ -1690,6 +1690,24 @@ __global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------- peer-write exchange: the consumer's wait
+// One wave: lane l re-reads flags[l] (system scope: the writers are other devices, or other processes on this one) until all
+// n values have reached `value`; a stream parked on it goes on when every rank's rows of the step have landed.
+__global__ void k_wait_flags(const unsigned long long *flags, int n, unsigned long long value, int spin_limit, int *fail) {
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  const int l = threadIdx.x;
+  for (int spins = 0;; ++spins) {
+    const unsigned long long v = l < n ? __hip_atomic_load((gu64 *)(flags + l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : value;
+    if (__all(v >= value)) break;
+    if (spins > spin_limit) {   // (wave-uniform)
+      if (l == 0 && fail) *fail = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __threadfence_system();
+}
+
 // d_loss[0] = sum_i loss_i / M   (SVGD.py:125); `fail` (the resident sweep's workgroups did not meet): NaN, counted
 __global__ void k_svgd_loss(const float *loss, int n_local, int M, float *out, int *fail, int *nonfinite) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

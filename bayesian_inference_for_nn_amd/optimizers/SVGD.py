@@ -74,6 +74,11 @@ class SVGD(Optimizer):
         # run on a multi-GPU node.  PYZ_SVGD_SHARD_GRAM=1 or the kwarg opts in.
         self._shard_gram = (bool(kwargs.get("shard_gram", os.environ.get("PYZ_SVGD_SHARD_GRAM", "0") == "1"))
                             and self._sharded and 8 % world == 0 and self._M % 4 == 0 and self._M <= 64)
+        # gather: "rccl" (all_gather_into_tensor) or "p2p" -- every rank writes its rows straight into its peers' matrices
+        # (parallel.PeerGather; opt-in: exercised with two processes on one GPU only)
+        self._gather = str(kwargs.get("gather", os.environ.get("PYZ_SVGD_GATHER", "rccl"))).lower()
+        if self._gather not in ("rccl", "p2p"):
+            raise ValueError("gather must be 'rccl' or 'p2p'")
         # every rank draws the same batches and the same particle initialisation: one base seed for all
         self._setup_backend(seed=kwargs.get("seed"), max_particles=self._n_local, chain_per_rank=False)
         self._rank, self._world = rank, world
@@ -97,6 +102,11 @@ class SVGD(Optimizer):
         self._adam_v = torch.zeros((self._n_local, self._D), device="cuda")
         self._loss_dev = torch.zeros(1, device="cuda")
         self._aux = None
+        self._peer = None
+        if self._sharded and self._gather == "p2p":
+            self._peer = parallel.PeerGather(self._M, self._D)
+            self._xseq = 0                                      # exchanges so far (its own count: result() exchanges once more)
+            self._shard_gram = False
         if self._shard_gram:
             per = 8 // world
             self._g_lo, self._g_hi = rank * per, (rank + 1) * per
@@ -139,7 +149,13 @@ class SVGD(Optimizer):
         # phase 1 -- the loss gradients -- needs the local rows only; the kernel matrix needs the snapshot only; the
         # combine (phi, Adam) needs both.  Several ranks: the all-gather is the one exchange step of the path.
         work = None
-        if self._sharded:
+        if self._peer is not None:
+            # peer-write exchange: this rank's rows go out on the exchange stream; the first reader of the gathered matrix
+            # waits for every rank's flag of this step (parked on ITS stream, below)
+            self._xseq += 1
+            self._all = self._peer.post(self._local, self._row0, self._xseq)
+            snapshot, target, cur = self._all, self._local, self._local
+        elif self._sharded:
             work = parallel.all_gather_rows(self._local, self._all, async_op=self._overlap_gather,
                                             force_collective=self._world == 1)
             snapshot, target, cur = self._all, self._local, self._local
@@ -151,9 +167,11 @@ class SVGD(Optimizer):
                  and self._plan.svgd_tile_shape(self._n_local, self._M, self._row0))
         if split:
             main, aux = torch.cuda.current_stream(), self._aux_stream()
-            if work is not None:
+            if self._peer is not None:
+                self._peer.wait(self._xseq, stream=aux)         # the aux stream waits for every rank's rows ...
+            elif work is not None:
                 with torch.cuda.stream(aux):
-                    work.wait()                                 # the aux stream waits for the gather ...
+                    work.wait()                                 # ... for the gather ...
             else:
                 aux.wait_stream(main)                           # ... or for what wrote the snapshot
             if self._shard_gram:
@@ -163,12 +181,17 @@ class SVGD(Optimizer):
             done = aux.record_event()
             self._plan.svgd_gradients(cur, self._x_dev, self._y_dev, batch=b, row_idx=idx)
             main.wait_event(done)
+            if self._peer is not None:
+                main.wait_event(self._peer.copied)              # (the combine rewrites the rows the exchange stream sent)
             if work is not None:
                 work.wait()                                     # (the combine reads the snapshot too)
             self._plan.svgd_combine(target, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
                                     self._step, self._loss_dev)
         else:
             self._plan.svgd_gradients(cur, self._x_dev, self._y_dev, batch=b, row_idx=idx)
+            if self._peer is not None:
+                self._peer.wait(self._xseq)
+                torch.cuda.current_stream().wait_event(self._peer.copied)
             if work is not None:
                 work.wait()
             self._plan.svgd_sweep(target, snapshot, self._row0, self._adam_m, self._adam_v, self._lr, self._gamma,
@@ -205,7 +228,13 @@ class SVGD(Optimizer):
     def result(self):
         import torch
         from .. import parallel
-        if self._sharded:
+        if self._peer is not None:
+            self._xseq += 1                                     # one more exchange: the rows of the last step
+            self._all = self._peer.post(self._local, self._row0, self._xseq)
+            self._peer.wait(self._xseq)
+            torch.cuda.synchronize()
+            self._peer.check()
+        elif self._sharded:
             parallel.all_gather_rows(self._local, self._all, force_collective=self._world == 1)
         P = self._all.cpu().numpy()
         ensemble = Ensemble()

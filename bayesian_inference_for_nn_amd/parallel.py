@@ -89,6 +89,73 @@ def all_gather_rows(local, out, async_op: bool = False, force_collective: bool =
     return work if async_op else None
 
 
+class PeerGather:
+    """The exchange step of the sharded SVGD run WITHOUT a collective library ("verify a direct
+    algorithm, else a peer-write fallback"): every rank writes its rows straight into every peer's gathered matrix --
+    device memory of the peers mapped into this process through IPC handles, i.e. stores over xGMI -- and then its slot of
+    the peer's flag array with the step number; the consumer parks ``pyz_wait_flags`` on the stream that reads the matrix.
+    One hop per step, 7 x 5 MB in parallel over the 7 links of a GPU instead of a ring's 7 dependent hops.
+    Two gathered matrices are used in turn: a rank sends its rows of step s + 1 only after it holds every rank's flag of
+    step s (it needs them for its own update), and a rank raises that flag only after it has finished reading step s - 1 --
+    so nobody still reads the matrix that step s + 1 overwrites.  Ranks must be processes of ONE node that see the same
+    device numbering (torchrun's default).  Exercised with two processes sharing one GPU (tests/test_gpu_multirank.py);
+    **not yet run between two devices**: opt-in (``SVGD(gather="p2p")`` / ``PYZ_SVGD_GATHER=p2p``)."""
+
+    def __init__(self, n_rows: int, width: int, device=None):
+        import torch
+        import torch.distributed as dist
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.rank, self.world = world_info()
+        if self.world > 64:
+            raise ValueError("PeerGather: at most 64 ranks")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.buf = torch.zeros((2, n_rows, width), device=dev)            # the two gathered matrices, used in turn
+        self.flags = torch.zeros((2, 64), dtype=torch.int64, device=dev)  # [matrix][rank]: the last step whose rows have landed
+        self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._seq_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.comm = torch.cuda.Stream(device=dev)
+        self.copied = None
+        torch.cuda.synchronize()
+        self.peer_buf, self.peer_flags = [self.buf] * self.world, [self.flags] * self.world
+        if self.world > 1:
+            mine = (reduce_tensor(self.buf), reduce_tensor(self.flags))
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine)
+            self.peer_buf, self.peer_flags = [], []
+            for r, ((fb, ab), (ff, af)) in enumerate(everyone):
+                self.peer_buf.append(self.buf if r == self.rank else fb(*ab))
+                self.peer_flags.append(self.flags if r == self.rank else ff(*af))
+            dist.barrier()                                                # every rank holds every mapping before the first write
+
+    def post(self, local, row0: int, step: int):
+        """Write `local` (this rank's rows, final on the current stream) into rows [row0, row0 + n) of everyone's matrix
+        step & 1, then this rank's flag.  Runs on the exchange stream; `self.copied` marks the end of its reads of `local`."""
+        import torch
+        b, n = step & 1, local.shape[0]
+        self.comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self._seq_dev.fill_(step)
+            for r in range(self.world):                                   # (own matrix first in rank order: a plain copy)
+                self.peer_buf[r][b, row0:row0 + n].copy_(local, non_blocking=True)
+            self.copied = self.comm.record_event()
+            for r in range(self.world):
+                self.peer_flags[r][b, self.rank:self.rank + 1].copy_(self._seq_dev, non_blocking=True)
+        return self.buf[b]
+
+    def wait(self, step: int, stream=None, spin_limit: int = 1 << 22):
+        """Park the wait for every rank's rows of `step` on `stream` (default: the current one)."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _lib.check(_lib.load().pyz_wait_flags(C.c_void_p(self.flags[step & 1].data_ptr()), self.world, int(step), int(spin_limit),
+                                              C.c_void_p(self.fail.data_ptr()), C.c_void_p(st.cuda_stream)))
+
+    def check(self):
+        if int(self.fail.item()) != 0:
+            raise RuntimeError("PeerGather: a rank's rows did not arrive (pyz_wait_flags gave up)")
+
+
 def sum_over_ranks(t):
     import torch.distributed as dist
     if world_info()[1] > 1:

@@ -363,6 +363,10 @@ def bench_svgd(args, rank, world, backend, dev):
     aux = torch.cuda.Stream()
     split = sweep == "jacobi" and plan.svgd_tile_shape(n_local, M, row0) and os.environ.get("PYZ_SVGD_OVERLAP_KM", "1") == "1"
     overlap_gather = os.environ.get("PYZ_SVGD_OVERLAP_GATHER", "0") == "1"      # async all-gather: opt-in (never run on a node yet)
+    # PYZ_SVGD_GATHER=p2p: every rank writes its rows straight into its peers' matrices (parallel.PeerGather) instead of the
+    # RCCL all-gather -- opt-in, exercised with two processes on one GPU only
+    peer = parallel.PeerGather(M, D, device=dev) if (sharded and os.environ.get("PYZ_SVGD_GATHER", "rccl").lower() == "p2p") else None
+    xseq = {"n": 0}
 
     def one_step(s, ev=None):
         """ev: optional dict of lists that receives (start, end) event pairs per phase of this step."""
@@ -375,7 +379,10 @@ def bench_svgd(args, rank, world, backend, dev):
             return e
         t_a = mark() if ev is not None else None
         work = None
-        if sharded:
+        if peer is not None:
+            xseq["n"] += 1
+            snapshot, target, cur = peer.post(buf["local"], row0, xseq["n"]), buf["local"], buf["local"]
+        elif sharded:
             work = parallel.all_gather_rows(buf["local"], buf["all"], async_op=overlap_gather)
             snapshot, target, cur = buf["all"], buf["local"], buf["local"]
         elif sweep == "jacobi":
@@ -384,7 +391,9 @@ def bench_svgd(args, rank, world, backend, dev):
             snapshot = target = cur = buf["all"]
         t_b = mark() if ev is not None else None          # (synchronous gather: it sits on the main stream between t_a and t_b)
         if split:
-            if work is not None:
+            if peer is not None:
+                peer.wait(xseq["n"], stream=aux)
+            elif work is not None:
                 with torch.cuda.stream(aux):
                     work.wait()
             else:
@@ -396,6 +405,8 @@ def bench_svgd(args, rank, world, backend, dev):
             plan.svgd_gradients(cur, x, y, batch=sizes[s], row_idx=idx[s])
             t_c = mark() if ev is not None else None
             main.wait_event(done)
+            if peer is not None:
+                main.wait_event(peer.copied)
             if work is not None:
                 work.wait()
             plan.svgd_combine(target, snapshot, row0, am, av, SVGD_LR, 1.0, state["t"], loss)
@@ -403,6 +414,9 @@ def bench_svgd(args, rank, world, backend, dev):
             k0 = k1 = None
             plan.svgd_gradients(cur, x, y, batch=sizes[s], row_idx=idx[s])
             t_c = mark() if ev is not None else None
+            if peer is not None:
+                peer.wait(xseq["n"])
+                main.wait_event(peer.copied)
             if work is not None:
                 work.wait()
             plan.svgd_sweep(target, snapshot, row0, am, av, SVGD_LR, 1.0, state["t"], loss, sweep=sweep)
@@ -423,6 +437,8 @@ def bench_svgd(args, rank, world, backend, dev):
 
     dt = timed_region(lambda: steps(0, args.warmup), lambda: steps(args.warmup, args.steps), world, backend, dev)
     plan.check_finite()
+    if peer is not None:
+        peer.check()
     total_loss = loss.clone()
     parallel.sum_over_ranks(total_loss)
     step_us = dt / args.steps * 1e6
@@ -474,7 +490,7 @@ def bench_svgd(args, rank, world, backend, dev):
         "config": {"workload": f"SVGD, {M} particles of MLP 784->200->10 (D=159010), batch 1024 replicated, {sweep} sweep, "
                                "gamma 1, prior N(0,1) start, eager launches",
                    "final_loss": round(float(total_loss.item()), 6),
-                   "kernel_matrix_on_second_stream": bool(split), "async_gather": bool(overlap_gather and sharded),
+                   "kernel_matrix_on_second_stream": bool(split), "async_gather": bool(overlap_gather and sharded), "exchange": "peer writes + flags (parallel.PeerGather)" if peer is not None else ("RCCL all-gather" if sharded else None),
                    "rccl_knobs_to_try": "NCCL_ALGO=Tree|Ring, NCCL_PROTO=Simple|LL|LL128, NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS: "
                                         "compare phases_us_per_rank.gather across runs",
                    "parallelism": (f"particles sharded x{args.gpus} ({n_local} per GPU), one all-gather of the (64, D) matrix "

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYZ_VERSION 301 /* 0.3.1 */
+#define PYZ_VERSION 302 /* 0.3.2 */
 
 #define PYZ_OK 0
 #define PYZ_E_INVALID (-1) /* bad argument / unsupported combination */
@@ -311,6 +311,14 @@ int pyz_free(void *d_ptr);
 int pyz_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int pyz_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int pyz_sync(void *stream);
+
+/* ---- exchange step of the sharded SVGD run without a collective library ("verify a direct algorithm, else a
+ * peer-write fallback"): every rank WRITES its rows straight into every peer's gathered matrix (peer-mapped memory over
+ * xGMI, the caller's copies) and then its slot of the peer's flag array; a consumer parks this on the stream that reads the
+ * gathered matrix: the stream goes on once d_flags[0 .. n) are all >= value (system-scope loads, one wave), i.e. once
+ * every rank's rows of that step have landed.  Gives up after spin_limit polls without progress: *d_fail (optional) is set to
+ * 1 and the stream goes on.  PYZ_E_INVALID for n outside [1, 64]. */
+int pyz_wait_flags(const uint64_t *d_flags, int n, uint64_t value, int spin_limit, int *d_fail, void *stream);
 
 /* ---- measurement hook (bench.py roofline leg): launch `iters` times ONE kernel of the
  * gradient step on the workspace left by the last pyz_mlp_loss_grad call with the same

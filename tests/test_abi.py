@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.pyz_version() == _lib.header_version() == 301
+    assert lib.pyz_version() == _lib.header_version() == 302
     assert isinstance(lib.pyz_device_count(), int)
 
 

@@ -165,6 +165,59 @@ def test_verbose_on_one_rank_only_pairs_the_same_collectives(gpu_device):
     assert len(ret[0][1]) == 2 and ret[0][1] == ret[1][1]
 
 
+# ------------------------------------------------------------------ the peer-write exchange (no collective library)
+def _p2p_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = rank % torch.cuda.device_count()          # two devices where the node has them, else both ranks on the one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bayesian_inference_for_nn_amd import synth
+        from bayesian_inference_for_nn_amd.datasets import Dataset
+        from bayesian_inference_for_nn_amd.distributions import GaussianPrior
+        from bayesian_inference_for_nn_amd.losses import SparseCategoricalCrossentropy
+        from bayesian_inference_for_nn_amd.nn import sequential_json
+        from bayesian_inference_for_nn_amd.optimizers import SVGD
+        from bayesian_inference_for_nn_amd.optimizers.hyperparameters import HyperParameters
+        cfg = sequential_json(2, [16, 2], ["relu", "softmax"])
+        x, y = synth.moons(500, seed=42)
+        ds = Dataset((x, y), SparseCategoricalCrossentropy, "Classification", seed=5)
+        runs = {}
+        for name, kw in (("whole", dict(shard=False, sweep="jacobi")), ("p2p", dict(gather="p2p")),
+                         ("p2p_one_stream", dict(gather="p2p", overlap_kernel_matrix=False))):
+            opt = SVGD()
+            opt.compile(HyperParameters(lr=0.05, M=8, batch_size=100), cfg, ds, verbose=False, prior=GaussianPrior(0.0, 0.3),
+                        seed=77, **kw)
+            for _ in range(13):
+                opt.step()
+            ens, tl, _ = opt.result()
+            runs[name] = (np.stack([m.weights_flat for m in ens]), [float(v) for v in tl], opt._peer is not None)
+            dist.barrier()
+        ret[rank] = {"peer": [runs[k][2] for k in runs],
+                     "diff": {k: float(np.abs(runs[k][0] - runs["whole"][0]).max()) for k in runs},
+                     "loss_diff": {k: float(np.abs(np.asarray(runs[k][1]) - np.asarray(runs["whole"][1])).max()) for k in runs}}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_their_rows_by_peer_writes(gpu_device):
+    """SVGD(gather="p2p"): every rank writes its rows into the other's gathered matrix through an IPC mapping and raises its
+    flag; the reader parks pyz_wait_flags on the stream that reads the matrix (parallel.PeerGather).  Two processes (on two
+    devices where the node has them, else sharing the one GPU: the mappings, the flags, the two matrices used in turn and the
+    stream order are the real ones; the stores do not cross xGMI there).  Thirteen steps + the exchange in result(): the
+    particles and losses of the unsharded Jacobi run, bit for bit."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_p2p_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in (ret[0], ret[1]):
+        assert r["peer"] == [False, True, True]
+        assert all(v == 0.0 for v in r["diff"].values()), dict(r["diff"])
+        assert all(v == 0.0 for v in r["loss_diff"].values()), dict(r["loss_diff"])
+
+
 # ------------------------------------------------------------------ two ranks on two GPUs over RCCL (where a node has them)
 def _rccl_worker(rank, world, port, ret):
     import torch.distributed as dist
