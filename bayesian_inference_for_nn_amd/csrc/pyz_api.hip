@@ -313,6 +313,13 @@ void launch_head(pyz_mlp *m, const float *theta, long long theta_ps, int P, cons
     static const int rw_rows = pyz_env_int("PYZ_HEAD_RW_ROWS", 32768);
     const int RW = (long long)P * grid_batch >= rw_rows ? 4 : 1;
     const dim3 grid((unsigned)cdiv(cdiv(grid_batch, RW), 4), P), block(256);
+    if (g.n_hparts > 0) {   // behind a split-reduction forward (ksplit_for: UT == 4, at most 16 classes, one chain)
+      if (NP == 4) PYZ_LAUNCH((k_head_rows<4, 4, 1, true>), grid, block, 0, st, g);
+      else if (NP == 8) PYZ_LAUNCH((k_head_rows<4, 8, 1, true>), grid, block, 0, st, g);
+      else if (NP == 12) PYZ_LAUNCH((k_head_rows<4, 12, 1, true>), grid, block, 0, st, g);
+      else PYZ_LAUNCH((k_head_rows<4, 16, 1, true>), grid, block, 0, st, g);
+      return;
+    }
 #define PYZ_HEAD_ROWS_CASE(U, C)                                                               \
   if (UT == U && NP == C) {                                                                    \
     if (RW == 4) PYZ_LAUNCH((k_head_rows<U, C, 4>), grid, block, 0, st, g);                     \

@@ -311,7 +311,10 @@ __device__ __forceinline__ void pyz_head_load_w(const HeadArgs &g, const int p, 
 // The head of ONE batch row m by ONE wave (lane l).  PRELOADED: W already holds the wave's share of [W; b] (several
 // rows per wave); else it is fetched here, behind the row's own loads (one row per wave: the order of round 1 --
 // with the 48 strided [W; b] loads in front of them the row's input and label chain start 0.4 us later).
-template <int UT, int NP, bool PRELOADED>
+// HP: the hidden layer arrives as the partial sums of a split-reduction forward (g.hparts; only instantiated for the shapes
+// that path takes -- as a run-time branch it cost every instantiation 35 registers: k_head_rows<4, 12, 4> fell from four to
+// three waves per SIMD and from 60 to 76 us at C5)
+template <int UT, int NP, bool PRELOADED, bool HP = false>
 __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch, const long long row_off, const int p,
                                              const int m, const int l, PyzHeadW<UT, NP> &W) {
   const int K = g.K, N = g.N;
@@ -323,7 +326,7 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
   // into whole-vector copies).
   const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(hp), 0, K * 4, 0x00020000);
   float hv[UT], z[NP];
-  if (g.n_hparts > 0) {
+  if constexpr (HP) {
     // the hidden layer as raw partial sums of a split reduction: eight loads per unit in flight together (splits past
     // n_hparts are out of range: zero), summed in split order; then bias and activation; the row goes to h_store
     const float *pp = g.hparts + (long long)m * K;
@@ -466,7 +469,7 @@ __device__ __forceinline__ void pyz_head_row(const HeadArgs &g, const int batch,
 // RW = batch rows per wave: 1 when the launch has few rows (a single chain: every row its own wave, the chip is
 // barely filled as it is), 4 when there are tens of thousands (64 particles x 1024 rows): the wave's share of
 // [W; b] -- UT x NP strided loads, most of the kernel's memory instructions -- is then fetched once for four rows.
-template <int UT, int NP, int RW = 1>
+template <int UT, int NP, int RW = 1, bool HP = false>
 __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   PYZ_STAMP(1, 0);
   const int w = pyz_wave_id(), l = threadIdx.x & 63;
@@ -480,7 +483,7 @@ __global__ void __launch_bounds__(256) k_head_rows(HeadArgs g) {
   }
   PyzHeadW<UT, NP> W;
   if (RW == 1) {
-    pyz_head_row<UT, NP, false>(g, batch, ctl.row_off, p, m0, l, W);
+    pyz_head_row<UT, NP, false, HP>(g, batch, ctl.row_off, p, m0, l, W);
     return;
   }
   pyz_head_load_w<UT, NP>(g, p, l, W);
