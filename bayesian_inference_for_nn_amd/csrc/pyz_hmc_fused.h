@@ -267,7 +267,9 @@ __device__ double pyz_hf_loss_grad(const HmcFusedArgs &a, const float *q, float 
     // the rows left over go one at a time.  (k_hmc_resident: a masked, clamped trip of four rows was ~200 instructions,
     // 6 500 of 17 500 cycles per gradient evaluation.)  Eight rows where the registers allow it (the 256-thread slice
     // kernels on a narrow model), two for the widest instantiation.
-    constexpr int RB = (MI + MC > 8) ? 2 : ((WAVES <= 8 && MI + MC <= 4) ? 8 : 4);
+    // (the widest records in the sixteen-wave kernel, 128 registers per lane: one row per trip -- with two, k_hmc_fused<8, 8, relu>
+    //  spilled two registers to scratch)
+    constexpr int RB = (MI + MC > 12 && WAVES > 8) ? 1 : (MI + MC > 8) ? 2 : ((WAVES <= 8 && MI + MC <= 4) ? 8 : 4);
     auto row_terms = [&](const float (&xv)[MI], const float (&dv)[MC]) {
       float pre = bj, dh = 0.0f;
 #pragma unroll
