@@ -421,9 +421,13 @@ void launch_wgrad_all(pyz_mlp *m, int P, const float *x, const int32_t *row_idx,
 inline float *batch_buf(pyz_mlp *m, int slot) { return m->xb + (size_t)slot * m->max_batch * m->dims[0]; }
 
 // chained runs whose batches are assembled one step ahead (PrepArgs, pyz_fused.h): single chain, fused path, a hidden layer
+// ... and a weight-gradient launch that leaves CUs idle for the copy: with more tiles than CUs (C4: 507) the workers only
+// take CUs from the tiles (72.6 against 71.7 us per step at C4; C2, 182 tiles: 24.4 against 26.7 the other way).
+// PYZ_BATCH_AHEAD=2 forces it on for every shape.
 inline bool batch_ahead(const pyz_mlp *m, const int32_t *row_idx) {
   static const int on = pyz_env_int("PYZ_BATCH_AHEAD", 1);
-  return on && can_fuse(m) && m->L > 1 && row_idx != nullptr;
+  if (!on || !can_fuse(m) || m->L <= 1 || row_idx == nullptr) return false;
+  return on == 2 || wgrad_tiles(m) + 24 <= pyz_cu_count();
 }
 
 PrepArgs prep_args(pyz_mlp *m, const float *x, const int32_t *row_idx, int grid_batch, long long row_stride, int dst_slot) {
