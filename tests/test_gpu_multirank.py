@@ -170,7 +170,9 @@ def _p2p_worker(rank, world, port, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dev = rank % torch.cuda.device_count()          # two devices where the node has them, else both ranks on the one GPU
+    # both ranks on device 0 (the configuration this exchange has been verified in); PYZ_TEST_P2P_TWO_DEVICES=1 puts them
+    # on two devices of a node that has them (stores over xGMI: not yet run anywhere)
+    dev = rank % torch.cuda.device_count() if os.environ.get("PYZ_TEST_P2P_TWO_DEVICES", "0") == "1" else 0
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -204,9 +206,9 @@ def _p2p_worker(rank, world, port, ret):
 
 def test_two_ranks_exchange_their_rows_by_peer_writes(gpu_device):
     """SVGD(gather="p2p"): every rank writes its rows into the other's gathered matrix through an IPC mapping and raises its
-    flag; the reader parks pyz_wait_flags on the stream that reads the matrix (parallel.PeerGather).  Two processes (on two
-    devices where the node has them, else sharing the one GPU: the mappings, the flags, the two matrices used in turn and the
-    stream order are the real ones; the stores do not cross xGMI there).  Thirteen steps + the exchange in result(): the
+    flag; the reader parks pyz_wait_flags on the stream that reads the matrix (parallel.PeerGather).  Two processes sharing one
+    GPU (the mappings, the flags, the two matrices used in turn and the stream order are the real ones; the stores do not
+    cross xGMI there -- PYZ_TEST_P2P_TWO_DEVICES=1 puts the ranks on two devices).  Thirteen steps + the exchange in result(): the
     particles and losses of the unsharded Jacobi run, bit for bit."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
