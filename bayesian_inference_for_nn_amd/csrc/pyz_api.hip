@@ -598,7 +598,8 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     if (rc != PYZ_OK) return fail(rc);
   }
   // a single chain's one hidden layer of <= 200 units (C2): room for the partial sums of the split-reduction forward
-  if (m->L == 2 && m->dims[1] > 192 && m->dims[1] <= 200) {
+  // (only when the opt-in is set when the plan is created: PYZ_FWD_KSPLIT >= 2)
+  if (m->L == 2 && m->dims[1] > 192 && m->dims[1] <= 200 && pyz_env_int("PYZ_FWD_KSPLIT", 0) >= 2) {
     const int rc = ensure_bytes(&m->x.fwd_part, &m->x.fwd_part_cap, sizeof(float) * (size_t)8 * max_batch * m->dims[1], m);
     if (rc != PYZ_OK) return fail(rc);
   }

@@ -144,6 +144,12 @@ def test_c2_sgld_graph_run_full_shape(eng, monkeypatch, n_steps, ksplit):
     close(sq, st.sq_mean, what="sq_mean")
     assert plan.last_run_path() == ("graph", n_steps)       # every step ran inside a replayed graph
     assert plan.last_run_graph_launches() == (3 if n_steps == 70 else 1)
+    # which forward the run's steps launch (a probe makes the same run eager)
+    with torch.cuda.stream(stream):
+        with eng.KernelProbe(32) as kp:
+            plan.sgld_run(th, mean, sq, xd, yd, idxd, sizes[:2], list(lrs[:2]), 0, 99, losses, use_graph=True)
+    stream.synchronize()
+    assert any(n.startswith("k_dense_fwd_ring") for n, _ in kp.launches) == (ksplit > 0), kp.launches
     plan.close()
 
 
