@@ -1320,6 +1320,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
   // -- the K row of particle i, while the first rows are on their way (its partials were requested first)
   double kd[64];
   float ksum = 0.0f;
+  double ksd = 0.0;   // sum_j K_ij in float64, j ascending: sum_j K_ij (x_i - x_j) = x_i ksd - sum_j K_ij x_j (one FMA per term)
   if (i >= 0) {
     {  // squared distances of row i: the partials of a row are summed by 8 threads (stride-8 slices), fixed order
       double s0 = 0.0, s1 = 0.0;
@@ -1345,6 +1346,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     for (int j = 0; j < 64; ++j) {
       kd[j] = sd[j];
       ksum += (float)kd[j];   // (+0.0f past M: the sum over j < M, same order)
+      ksd += kd[j];
     }
   }
   PYZ_GS_STAMP(3);
@@ -1367,7 +1369,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
     if (i >= 0) {  // repulsion term of this row, in float64 like the kernel values (see below)
 #pragma unroll
       for (int q = 0; q < PYZ_GS_E; ++q) {
-        rep[q] = fma(kd[j], (double)xi[q] - (double)x[j][q], rep[q]);
+        rep[q] = fma(kd[j], (double)x[j][q], rep[q]);
         asm volatile("" : "+v"(rep[q]));
       }
     }
@@ -1382,7 +1384,7 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
 #pragma unroll
     for (int q = 0; q < PYZ_GS_E; ++q) {
       float m = am[q], v = av[q], xn;
-      pyz_svgd_gs_adam(ksum, gi[q], rep[q], g.gamma, M, xi[q], g.lr_t, m, v, xn);
+      pyz_svgd_gs_adam(ksum, gi[q], fma((double)xi[q], ksd, -rep[q]), g.gamma, M, xi[q], g.lr_t, m, v, xn);
       if (in[q]) {
         const long long o = (long long)i * D + e[q];
         g.adam_m[o] = m;
@@ -1598,9 +1600,12 @@ __global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
         }
         const double kv = lane < M ? pyz_gs_join(lo, hi) : 0.0;
         sd[lane] = kv;
-        float ks = 0.0f;                 // sum_j (float) K_ij, j ascending (+0.0f past M): once per workgroup
-        const float kf = (float)kv;
-        for (int j = 0; j < 64; ++j) ks += __shfl(kf, j, 64);
+        // sum_j (float) K_ij, j ascending (+0.0f past M), once per workgroup: lane j's value as a SCALAR operand (v_readlane
+        // with a constant lane; a shuffle by a loop counter is an LDS permute per term on the path every workgroup waits on)
+        float ks = 0.0f;
+        const int kfb = __builtin_bit_cast(int, (float)kv);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) ks += __builtin_bit_cast(float, __builtin_amdgcn_readlane(kfb, j));
         if (lane == 0) sd[64] = (double)ks;
       }
       pyz_lds_barrier();
@@ -1610,21 +1615,23 @@ __global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
       }
       PYZ_LAP(lap, 1);
       const float ksum = (float)sd[64];
+      double ksd = 0.0;   // sum_j K_ij in float64, j ascending (every thread: 64 adds beside its FMAs)
       double rep[PYZ_GS_E];
 #pragma unroll
       for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
 #pragma unroll
       for (int j = 0; j < 64; ++j) {
         const double kdj = sd[j];
+        ksd += kdj;
 #pragma unroll
-        for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = fma(kdj, (double)xi[q] - (double)x[j][q], rep[q]);
+        for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = fma(kdj, (double)x[j][q], rep[q]);
       }
       double acc_i = 0.0;
       float xn[PYZ_GS_E];
 #pragma unroll
       for (int q = 0; q < PYZ_GS_E; ++q) {
         float m = am[q], v = av[q];
-        pyz_svgd_gs_adam(ksum, gi[q], rep[q], g.gamma, M, xi[q], g.lr_t, m, v, xn[q]);
+        pyz_svgd_gs_adam(ksum, gi[q], fma((double)xi[q], ksd, -rep[q]), g.gamma, M, xi[q], g.lr_t, m, v, xn[q]);
         if (in[q]) {
           const long long o = (long long)i * D + e[q];
           g.adam_m[o] = m;
