@@ -613,6 +613,9 @@ int pyz_mlp_create(int n_layers, const int32_t *h_dims, const int32_t *h_acts, i
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs_resident), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pyz_svgd_gs_res_lds_bytes()) != hipSuccess)
       return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs_resident) failed"));
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gs_resident2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)pyz_svgd_gs_res_lds_bytes()) != hipSuccess)
+      return fail(pyz_fail(PYZ_E_HIP, "hipFuncSetAttribute(k_svgd_gs_resident2) failed"));
     const int gr_lds = (int)pyz_svgd_gram_lds_bytes();
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_svgd_gram_tile<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, gr_lds) != hipSuccess ||
@@ -1768,16 +1771,20 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       // the whole sweep as ONE resident launch when its workgroups fit the chip at once (k_svgd_gs_resident); read per
       // call: tests flip it
       const int gs_reducers = cdiv(n_total, 8);   // workgroups that only sum columns of partials (k_svgd_gs_resident)
-      bool resident = pyz_env_int("PYZ_SVGD_GS_RESIDENT", 1) != 0 && ga.nblk + gs_reducers <= pyz_cu_count();
+      // (1: the partials of row i + 1 through the reducers behind the update of row i; 2: the distances one step early and the
+      //  one critical distance in a single hop, k_svgd_gs_resident2)
+      const int gs_res_mode = pyz_env_int("PYZ_SVGD_GS_RESIDENT", 1);
+      bool resident = gs_res_mode != 0 && ga.nblk + gs_reducers <= pyz_cu_count();
+      const void *gs_res_fn = gs_res_mode == 2 ? reinterpret_cast<const void *>(k_svgd_gs_resident2) : reinterpret_cast<const void *>(k_svgd_gs_resident);
       if (resident) {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_svgd_gs_resident), 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gs_res_fn, 256,
                                                          pyz_svgd_gs_res_lds_bytes()) != hipSuccess || per_cu < 1)
           resident = false;
       }
       if (resident) {
         pyz_mlp_full *fm = full(m);
-        const size_t gbytes = 256 + sizeof(unsigned long long) * 2 * (2 * (size_t)256 * 64 + 2 * 64);
+        const size_t gbytes = 256 + sizeof(unsigned long long) * 2 * (2 * (size_t)256 * 64 + 2 * 64 + 2 * 256);
         const size_t had = fm->x.gs_res_cap;
         if ((rc = ensure_bytes(&fm->x.gs_res_buf, &fm->x.gs_res_cap, gbytes, m))) return rc;
         if (fm->x.gs_res_cap != had)   // a fresh buffer: epoch and tags start at zero (the kernel's tags are >= 1 and only grow)
@@ -1797,8 +1804,10 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
         ra.fail = reinterpret_cast<int *>(gb + 64);
         ra.kgran = reinterpret_cast<unsigned long long *>(gb + 256);
         ra.pgran = ra.kgran + 2 * 64 * 2;
+        ra.cgran = ra.pgran + 2 * (size_t)256 * 64 * 2;
         ra.spin_limit = pyz_env_int("PYZ_SVGD_GS_SPIN_LIMIT", 1 << 20);
-        PYZ_LAUNCH(k_svgd_gs_resident, dim3(ga.nblk + gs_reducers), dim3(256), pyz_svgd_gs_res_lds_bytes(), st, ra);
+        if (gs_res_mode == 2) PYZ_LAUNCH(k_svgd_gs_resident2, dim3(ga.nblk + gs_reducers), dim3(256), pyz_svgd_gs_res_lds_bytes(), st, ra);
+        else PYZ_LAUNCH(k_svgd_gs_resident, dim3(ga.nblk + gs_reducers), dim3(256), pyz_svgd_gs_res_lds_bytes(), st, ra);
         PYZ_LAUNCH(k_svgd_loss, dim3(1), dim3(64), 0, st, loss, n_local, n_total, d_loss, ra.fail, m->nonfinite);
         PYZ_LAUNCH_CHECK();
         return PYZ_OK;

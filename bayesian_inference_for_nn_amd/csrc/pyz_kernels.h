@@ -1440,6 +1440,7 @@ struct SvgdGsResArgs {
   unsigned *epoch;             // [1] tags <= *epoch are stale; advanced by M per sweep (workgroup 0)
   unsigned long long *pgran;   // (2, nblk, 64, 2) granules {tag, low half} {tag, high half} of the partials
   unsigned long long *kgran;   // (2, 64, 2) granules of the kernel row
+  unsigned long long *cgran;   // (2, 256, 2) granules of the blocks' partials of the one critical distance (k_svgd_gs_resident2)
   int *fail;
   int spin_limit;
 };
@@ -1689,6 +1690,335 @@ __global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
       av[q] = g.adam_v[o];
       xnext[q] = inext + 1 < M ? g.all[(long long)(inext + 1) * D + e[q]] : 0.0f;
     }
+  }
+  if (b == 0 && tid == 0) *g.epoch = epoch0 + (unsigned)M;
+#ifdef PYZ_STAMPS
+  if (lane == 0 && b < PYZ_STAMP_BLOCKS)
+    for (int k = 0; k < 8; ++k) pyz_dbg_buf[3][b][w][k][0] = lap[k];
+#endif
+}
+
+// ---------------------------------------------------------------- resident Gauss-Seidel sweep, distances one step early
+// k_svgd_gs_resident's step i is a chain: K_i -> update of row i -> partials of row i + 1 -> reducers -> K_{i+1}: two cross-XCD
+// hops plus the reducer wave per particle.  But only ONE of the 64 squared distances of row i + 1 depends on the update of row i:
+// d(i + 1, i).  Here the partials of row i + 2 against every row are taken and sent through the reducers during step i (the
+// column of row i + 1, not yet updated, is ignored by its reducer), and the one critical distance goes in ONE hop: after updating
+// row i every workgroup publishes its block's partial of d(i + 1, i) (`cgran`), and every workgroup's first wave sums the nblk
+// partials itself -- in the reducers' order, eight stride-8 slices in block order -- and takes K_{i+1,i} = exp(-gamma d).  The
+// arithmetic is k_svgd_gs_resident's term by term (same partials, same orders of summation), so both give the same bits.
+// Slots by row parity as before: a workgroup that publishes partials of row i + 2 holds K_i, so every reducer is done with row
+// i's slot; the reducers publish K_{i+2} after every workgroup's partials of row i + 2, which each sent after reading K_i; a
+// workgroup that publishes its critical partial for row i + 1 has summed everyone's for row i, which each sent after summing
+// those for row i - 1.
+__global__ void __launch_bounds__(256) k_svgd_gs_resident2(SvgdGsResArgs g) {
+  extern __shared__ double gs_lds[];
+  double *red = gs_lds;                  // [64][PYZ_GS_PAD]
+  double *ps4 = red + 64 * PYZ_GS_PAD;   // [4][64]
+  double *cv = ps4 + 4 * 64;             // [8][32] the critical distance's partials, slice-major (first wave only)
+  double *sd = ps4 + 8 * 64;             // [64]
+  int *gave_up = reinterpret_cast<int *>(sd + 66);
+  const int tid = threadIdx.x, M = g.M, b = blockIdx.x, w = pyz_wave_id(), lane = tid & 63;
+  const long long D = g.D, base = (long long)b * (256 * PYZ_GS_E);
+  const int pj = tid & 63, pq = tid >> 6;
+  if (tid == 0) *gave_up = 0;
+  const unsigned epoch0 = *g.epoch;   // (left by the previous sweep's launch)
+  if (b >= g.nblk) {
+    // ---- a reducer workgroup: k_svgd_gs_resident's, except that row r's column r - 1 is not published
+    if (w != 0) return;
+    const int r = b - g.nblk, c = lane >> 3, sl = lane & 7, j = 8 * r + c;
+    for (int inext = 0; inext < M; ++inext) {
+      const unsigned tagn = epoch0 + 1u + (unsigned)inext;
+      const unsigned long long *pp = g.pgran + ((long long)(inext & 1) * g.nblk * 64 + min(j, M - 1)) * 2;
+      double sum = 0.0;
+      bool lost = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned long long lo[16], hi[16];
+        for (int spins = 0;;) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const unsigned long long *p = pp + (long long)min(sl + 8 * (16 * h + u), g.nblk - 1) * 128;
+            lo[u] = pyz_gs_load(p);
+            hi[u] = pyz_gs_load(p + 1);
+          }
+          unsigned bad = 0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) bad |= ((unsigned)(lo[u] >> 32) ^ tagn) | ((unsigned)(hi[u] >> 32) ^ tagn);
+          if (__all(bad == 0)) break;
+          if (++spins > g.spin_limit) {   // (wave-uniform)
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lost) break;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += sl + 8 * (16 * h + u) < g.nblk ? pyz_gs_join(lo[u], hi[u]) : 0.0;
+      }
+      if (lost) {   // the compute workgroups never showed up: they give up on their own polls
+        if (lane == 0) *g.fail = 1;
+        return;
+      }
+      const int l0 = lane & ~7;
+      const double s0 = __shfl(sum, l0, 64), s1 = __shfl(sum, l0 + 1, 64), s2 = __shfl(sum, l0 + 2, 64), s3 = __shfl(sum, l0 + 3, 64);
+      const double s4 = __shfl(sum, l0 + 4, 64), s5 = __shfl(sum, l0 + 5, 64), s6 = __shfl(sum, l0 + 6, 64), s7 = __shfl(sum, l0 + 7, 64);
+      if (sl == 0 && j < M && j != inext - 1) {
+        const double dsq = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        pyz_gs_store_f64(g.kgran + ((long long)(inext & 1) * 64 + j) * 2, tagn, exp(-(double)g.gamma * dsq));
+      }
+    }
+    return;
+  }
+  long long e[PYZ_GS_E];
+  bool in[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) {
+    e[q] = base + PYZ_GS_E * tid + q;
+    in[q] = e[q] < D;
+    e[q] = in[q] ? e[q] : D - 1;
+  }
+  const bool whole = base + (long long)PYZ_GS_E * 64 * (w + 1) <= D;  // all elements of this WAVE exist (scalar)
+  float x[64][PYZ_GS_E];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    if (whole) {
+      const pyz_gs_vec v = *reinterpret_cast<const pyz_gs_vec *>(g.all + (long long)min(j, M - 1) * D + e[0]);
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = v[q];
+    } else {
+      const float *row = g.all + (long long)min(j, M - 1) * D;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) x[j][q] = row[e[q]];
+    }
+  }
+  __syncthreads();   // gave_up is initialised
+#ifdef PYZ_STAMPS
+  unsigned long long lap[16] = {0};
+  PYZ_LAP(lap, 8);
+  lap[8] = 0;
+#else
+  unsigned long long *lap = nullptr;
+  (void)lap;
+#endif
+  // the first wave's granules of the NEXT step's kernel row, requested behind the distance arithmetic of send_row (a coherent
+  // load is a round trip across the XCDs: asked for at the top of the step it is paid in full even when the values are there)
+  unsigned long long plo = 0, phi = 0, pclo[4] = {0, 0, 0, 0}, pchi[4] = {0, 0, 0, 0};
+  bool pre = false;
+  // partial squared distances of a row (values xr) against every row as it stands -> this block's 64 sums -> the reducers
+  // (float64 differences and squares, SVGD.py:198-201; k_svgd_gs's sums in its order)
+  auto send_row = [&](const float (&xr)[PYZ_GS_E], const int row) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) {
+        const double df = in[q] ? (double)xr[q] - (double)x[j][q] : 0.0;
+        a = fma(df, df, a);
+      }
+      red[j * PYZ_GS_PAD + tid] = a;
+    }
+    PYZ_LAP(lap, 4);
+    pre = row >= 2;   // (step row - 1 >= 1 comes next: it has a critical distance, published by every block a pass ago)
+    if (w == 0 && pre) {
+      const int nx = row - 1;
+      const unsigned long long *kg = g.kgran + ((long long)(nx & 1) * 64 + lane) * 2;
+      const unsigned long long *cg = g.cgran + (long long)(nx & 1) * 512;
+      plo = pyz_gs_load(kg);
+      phi = pyz_gs_load(kg + 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int blk = min((lane & 7) + 8 * ((lane >> 3) + 8 * u), g.nblk - 1);
+        pclo[u] = pyz_gs_load(cg + 2 * blk);
+        pchi[u] = pyz_gs_load(cg + 2 * blk + 1);
+      }
+    }
+    pyz_lds_barrier();
+    {
+      const double *rp = red + pj * PYZ_GS_PAD + 64 * pq;
+      double s = 0.0;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += 16) {   // (the reads of a batch in flight together; the sum stays in order)
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = rp[t0 + t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += v[t];
+      }
+      ps4[pq * 64 + pj] = s;
+    }
+    pyz_lds_barrier();
+    if (w == 0) {
+      const double tot = lane < M ? (ps4[lane] + ps4[64 + lane]) + (ps4[128 + lane] + ps4[192 + lane]) : 0.0;
+      pyz_gs_store_f64(g.pgran + (((long long)(row & 1) * g.nblk + b) * 64 + lane) * 2, epoch0 + 1u + (unsigned)row, tot);
+    }
+    pyz_lds_barrier();   // (ps4 and red are free again)
+    PYZ_LAP(lap, 5);
+  };
+  // steps -2 and -1 only send rows 0 and 1 (row 1's column 0 waits for the update of row 0: the reducers leave it out)
+  float xi[PYZ_GS_E], xnext[PYZ_GS_E], xnn[PYZ_GS_E], gi[PYZ_GS_E], am[PYZ_GS_E], av[PYZ_GS_E];
+#pragma unroll
+  for (int q = 0; q < PYZ_GS_E; ++q) {
+    xnn[q] = x[0][q];
+    xi[q] = xnext[q] = gi[q] = am[q] = av[q] = 0.0f;
+  }
+  for (int i = -2; i < M; ++i) {
+    const int inext = i + 1;
+    float xn[PYZ_GS_E] = {0.0f, 0.0f, 0.0f};
+    if (i >= 0) {
+    // -- the kernel row of particle i: the reducers' granules, and the critical distance d(i, i - 1) from every block's partial
+    const unsigned tag = epoch0 + 1u + (unsigned)i;
+    if (w == 0) {
+      const unsigned long long *kg = g.kgran + ((long long)(i & 1) * 64 + lane) * 2;
+      const unsigned long long *cg = g.cgran + (long long)(i & 1) * 512;
+      const bool need_k = lane < M && lane != i - 1;
+      const int sl = lane & 7, c = lane >> 3;   // lane -> blocks sl + 8 (c + 8 u), u < 4
+      unsigned long long lo = plo, hi = phi, clo[4] = {pclo[0], pclo[1], pclo[2], pclo[3]}, chi[4] = {pchi[0], pchi[1], pchi[2], pchi[3]};
+      bool have = pre;   // (uniform) the first look is at what was requested a pass ago
+      for (int spins = 0;;) {
+        if (!have) {
+          lo = pyz_gs_load(kg);
+          hi = pyz_gs_load(kg + 1);
+          if (i >= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int blk = min(sl + 8 * (c + 8 * u), g.nblk - 1);
+              clo[u] = pyz_gs_load(cg + 2 * blk);
+              chi[u] = pyz_gs_load(cg + 2 * blk + 1);
+            }
+          }
+        }
+        have = false;
+        bool ok = !need_k || ((unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag);
+        if (i >= 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ok = ok && (unsigned)(clo[u] >> 32) == tag && (unsigned)(chi[u] >> 32) == tag;
+        }
+        if (__all(ok)) break;
+        if (++spins > g.spin_limit) {   // (wave-uniform)
+          *gave_up = 1;
+          *g.fail = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(PYZ_GS_POLL_SLEEP);
+      }
+      double kv = need_k ? pyz_gs_join(lo, hi) : 0.0;
+      if (i >= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = c + 8 * u;
+          cv[sl * 32 + k] = sl + 8 * k < g.nblk ? pyz_gs_join(clo[u], chi[u]) : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double s = 0.0;   // slice sl in block order (every lane: lanes 8 c + sl repeat lane sl)
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 16) {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = cv[sl * 32 + k0 + k];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) s += v[k];
+        }
+        const double s0 = __shfl(s, 0, 64), s1 = __shfl(s, 1, 64), s2 = __shfl(s, 2, 64), s3 = __shfl(s, 3, 64);
+        const double s4 = __shfl(s, 4, 64), s5 = __shfl(s, 5, 64), s6 = __shfl(s, 6, 64), s7 = __shfl(s, 7, 64);
+        const double dsq = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        if (lane == i - 1) kv = exp(-(double)g.gamma * dsq);
+      }
+      sd[lane] = kv;
+      float ks = 0.0f;
+      const int kfb = __builtin_bit_cast(int, (float)kv);
+#pragma unroll
+      for (int j = 0; j < 64; ++j) ks += __builtin_bit_cast(float, __builtin_amdgcn_readlane(kfb, j));
+      if (lane == 0) sd[64] = (double)ks;
+    }
+    pyz_lds_barrier();
+    if (*gave_up) {   // (uniform) the others never showed up: not resident together, or one of them gave up
+      if (b == 0 && tid == 0) *g.epoch = epoch0 + (unsigned)M;
+      return;
+    }
+    PYZ_LAP(lap, 0);
+    const float ksum = (float)sd[64];
+    double ksd = 0.0;   // sum_j K_ij in float64, j ascending
+    double rep[PYZ_GS_E];
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const double kdj = sd[j];
+      ksd += kdj;
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) rep[q] = fma(kdj, (double)x[j][q], rep[q]);
+    }
+    double acc_i = 0.0;
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      float m = am[q], v = av[q];
+      pyz_svgd_gs_adam(ksum, gi[q], fma((double)xi[q], ksd, -rep[q]), g.gamma, M, xi[q], g.lr_t, m, v, xn[q]);
+      if (in[q]) {
+        const long long o = (long long)i * D + e[q];
+        g.adam_m[o] = m;
+        g.adam_v[o] = v;
+        g.all[o] = xn[q];
+        const double df = (double)xnext[q] - (double)xn[q];
+        acc_i = fma(df, df, acc_i);
+      }
+    }
+    if (inext >= M) break;
+    PYZ_LAP(lap, 1);
+    // -- the critical partial: this block's sum of d(i + 1, i), the block reduction's column i alone
+    red[i * PYZ_GS_PAD + tid] = acc_i;
+    pyz_lds_barrier();
+    if (pj == i) {
+      const double *rp = red + i * PYZ_GS_PAD + 64 * pq;
+      double s = 0.0;
+#pragma unroll
+      for (int t0 = 0; t0 < 64; t0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = rp[t0 + t];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += v[t];
+      }
+      ps4[pq * 64 + i] = s;
+    }
+    pyz_lds_barrier();
+    if (tid == 0) {
+      const double tot = (ps4[i] + ps4[64 + i]) + (ps4[128 + i] + ps4[192 + i]);
+      pyz_gs_store_f64(g.cgran + (long long)(inext & 1) * 512 + 2 * b, epoch0 + 1u + (unsigned)inext, tot);
+    }
+    PYZ_LAP(lap, 2);
+    }   // (i >= 0)
+    // -- the next particle's operands (rows >= i + 1 are still the values the sweep started with): back behind the next wait
+    if (inext >= 0) {
+#pragma unroll
+      for (int q = 0; q < PYZ_GS_E; ++q) {
+        const long long o = (long long)inext * D + e[q];
+        gi[q] = g.grad[o];
+        am[q] = g.adam_m[o];
+        av[q] = g.adam_v[o];
+      }
+    }
+    // the register copy of row i (uniform i: a scalar jump into one of 64 three-move cases)
+#define PYZ_GS_PATCH(J) case J: _Pragma("unroll") for (int q = 0; q < PYZ_GS_E; ++q) x[J][q] = xn[q]; break;
+#define PYZ_GS_PATCH8(J) PYZ_GS_PATCH(J) PYZ_GS_PATCH(J + 1) PYZ_GS_PATCH(J + 2) PYZ_GS_PATCH(J + 3) PYZ_GS_PATCH(J + 4) PYZ_GS_PATCH(J + 5) PYZ_GS_PATCH(J + 6) PYZ_GS_PATCH(J + 7)
+    switch (i) {
+      PYZ_GS_PATCH8(0) PYZ_GS_PATCH8(8) PYZ_GS_PATCH8(16) PYZ_GS_PATCH8(24) PYZ_GS_PATCH8(32) PYZ_GS_PATCH8(40) PYZ_GS_PATCH8(48) PYZ_GS_PATCH8(56)
+      default: break;
+    }
+#undef PYZ_GS_PATCH8
+#undef PYZ_GS_PATCH
+    // -- partials of row i + 2 against the matrix as it now stands (its column i + 1 is the next step's critical distance)
+    PYZ_LAP(lap, 3);
+    pre = false;
+    if (i + 2 < M) send_row(xnn, i + 2);
+#pragma unroll
+    for (int q = 0; q < PYZ_GS_E; ++q) {
+      xi[q] = xnext[q];
+      xnext[q] = xnn[q];
+      xnn[q] = i + 3 < M ? g.all[(long long)(i + 3) * D + e[q]] : 0.0f;
+    }
+    PYZ_LAP(lap, 6);
   }
   if (b == 0 && tid == 0) *g.epoch = epoch0 + (unsigned)M;
 #ifdef PYZ_STAMPS

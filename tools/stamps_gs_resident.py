@@ -35,7 +35,12 @@ check(lib_.pyz_debug_stamps(buf, K * B * W * S * 2))
 raw = np.frombuffer(buf, dtype=np.uint64).reshape(K, B, W, S, 2).astype(np.int64)
 names = ["partials of row i+1 (64 rows)", "wait for K_i + barrier", "repulsion, Adam, patch", "barrier, column sums, barrier",
          "publish / reduce a column", "next operands (loop top)"]
-print("k_svgd_gs_resident at C5: cycles per particle (s_memtime ticks), wave w of workgroup b")
+NL = 6
+if os.environ.get("PYZ_SVGD_GS_RESIDENT", "1") == "2":   # k_svgd_gs_resident2 (distances one step early): its own laps
+    names = ["wait for K_i (reducers' 63 + the critical distance) + barrier", "repulsion, Adam", "critical partial: column sum, publish",
+             "next operands, patch", "partials of row i+2 (64 rows)", "barrier, column sums, publish, barriers", "rotate (loop end)"]
+    NL = 7
+print("resident Gauss-Seidel sweep at C5: cycles per particle (s_memtime ticks), wave w of workgroup b")
 for b, w in ((0, 0), (0, 1), (0, 2), (100, 0), (100, 1), (207, 0)):
-    lap = raw[3, b, w, :6, 0] / 64.0
+    lap = raw[3, b, w, :NL, 0] / 64.0
     print(f"  b={b:3d} w={w}: " + "  ".join(f"{n}: {v:7.0f}" for n, v in zip(names, lap)) + f"   sum {lap.sum():7.0f}")
