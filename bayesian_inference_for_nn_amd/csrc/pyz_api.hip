@@ -1770,7 +1770,8 @@ static int svgd_sweep_impl(pyz_mlp *m, float *d_particles, int n_local, const fl
       // (k_svgd_gs's 130 KB of dynamic LDS: allowed when the plan was created, pyz_mlp_create)
       // the whole sweep as ONE resident launch when its workgroups fit the chip at once (k_svgd_gs_resident); read per
       // call: tests flip it
-      const int gs_reducers = cdiv(n_total, 8);   // workgroups that only sum columns of partials (k_svgd_gs_resident)
+      // workgroups that only sum columns of partials: four columns each in k_svgd_gs_resident, eight in k_svgd_gs_resident2
+      const int gs_reducers = pyz_env_int("PYZ_SVGD_GS_RESIDENT", 1) == 2 ? cdiv(n_total, 8) : cdiv(n_total, 4);
       // (1: the partials of row i + 1 through the reducers behind the update of row i; 2: the distances one step early and the
       //  one critical distance in a single hop, k_svgd_gs_resident2)
       const int gs_res_mode = pyz_env_int("PYZ_SVGD_GS_RESIDENT", 1);

@@ -1420,8 +1420,10 @@ __global__ void __launch_bounds__(256) k_svgd_gs(SvgdGsArgs g) {
 // data-tagged granules (k_hmc_resident's hand-off: one aligned 8-byte write-through store {tag, half of a double}; the
 // consumer re-reads until the tags are the step's), in two hops:
 //   every workgroup publishes its block's partials of row i + 1 (after updating row i);
-//   the reducer of column j (one of cdiv(M, 8) extra workgroups that own no elements, eight columns each: a reducer wave that
-//   also carried a slice's arithmetic held every step back by its own) sums the nblk partials of d_{i+1,j} in k_svgd_gs's
+//   the reducer of column j (one of cdiv(M, 4) extra workgroups that own no elements, four columns each, sixteen lanes per
+//   column so that every lane has ONE batch of loads: a reducer wave that also carried a slice's arithmetic held every step
+//   back by its own, and eight lanes per column needed two batches in turn -- a second round trip on the chain every workgroup
+//   waits on, 2 200 cycles per particle) sums the nblk partials of d_{i+1,j} in k_svgd_gs's
 //   order, takes K_{i+1,j} = exp(-gamma d) and publishes it; every workgroup's first wave polls the 64 kernel values.
 // Everything else is k_svgd_gs<false>'s arithmetic in its order, so both forms give the same bits (with the per-launch
 // form's rows in ascending order: PYZ_SVGD_GS_ZIGZAG=0).  The partials of row i + 1 against the rows that do not change
@@ -1475,51 +1477,52 @@ __global__ void __launch_bounds__(256) k_svgd_gs_resident(SvgdGsResArgs g) {
   if (tid == 0) *gave_up = 0;
   const unsigned epoch0 = *g.epoch;   // (left by the previous sweep's launch)
   if (b >= g.nblk) {
-    // ---- a reducer workgroup (no elements of its own): columns 8 r .. 8 r + 7 of every row's squared distances, one wave
+    // ---- a reducer workgroup (no elements of its own): columns 4 r .. 4 r + 3 of every row's squared distances, one wave
     if (w != 0) return;
-    const int r = b - g.nblk, c = lane >> 3, sl = lane & 7, j = 8 * r + c;
+    // sixteen lanes per column: slice sl = the blocks sl, sl + 8, ... (k_svgd_gs's eight stride-8 slices), its first sixteen
+    // blocks on lane `half` = 0 and the rest on half = 1 -- every lane has ONE batch of loads (one round trip per particle on
+    // the chain every workgroup waits on; eight lanes per column needed two batches in turn); the sum stays in block order:
+    // the second half continues from the first half's sum
+    const int r = b - g.nblk, c = lane >> 4, sl = lane & 7, half = (lane >> 3) & 1, j = 4 * r + c;
     for (int inext = 0; inext < M; ++inext) {
       const unsigned tagn = epoch0 + 1u + (unsigned)inext;
       const unsigned long long *pp = g.pgran + ((long long)(inext & 1) * g.nblk * 64 + min(j, M - 1)) * 2;
-      // the nblk partials of d_{inext,j}: eight stride-8 slices in block order (the lanes of a column), combined as
-      // k_svgd_gs combines them.  Two batches of sixteen blocks: every load of a batch is issued before the first tag is
-      // looked at (a test per load makes them dependent round trips); blocks past the end repeat the last one.  (One batch of
-      // thirty-two and polls without the sleep: 4 000 cycles per particle SLOWER -- the polls of 216 workgroups get in the
-      // way of the stores they wait for.)
-      double sum = 0.0;
+      unsigned long long lo[16], hi[16];
       bool lost = false;
+      for (int spins = 0;;) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        unsigned long long lo[16], hi[16];
-        for (int spins = 0;;) {
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const unsigned long long *p = pp + (long long)min(sl + 8 * (16 * h + u), g.nblk - 1) * 128;
-            lo[u] = pyz_gs_load(p);
-            hi[u] = pyz_gs_load(p + 1);
-          }
-          unsigned bad = 0;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) bad |= ((unsigned)(lo[u] >> 32) ^ tagn) | ((unsigned)(hi[u] >> 32) ^ tagn);
-          if (__all(bad == 0)) break;
-          if (++spins > g.spin_limit) {   // (wave-uniform)
-            lost = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
+        for (int u = 0; u < 16; ++u) {
+          const unsigned long long *p = pp + (long long)min(sl + 8 * (16 * half + u), g.nblk - 1) * 128;
+          lo[u] = pyz_gs_load(p);
+          hi[u] = pyz_gs_load(p + 1);
         }
-        if (lost) break;
+        unsigned bad = 0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sum += sl + 8 * (16 * h + u) < g.nblk ? pyz_gs_join(lo[u], hi[u]) : 0.0;
+        for (int u = 0; u < 16; ++u) bad |= ((unsigned)(lo[u] >> 32) ^ tagn) | ((unsigned)(hi[u] >> 32) ^ tagn);
+        if (__all(bad == 0)) break;
+        if (++spins > g.spin_limit) {   // (wave-uniform)
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
       if (lost) {   // the compute workgroups never showed up: they give up on their own polls
         if (lane == 0) *g.fail = 1;
         return;
       }
-      const int l0 = lane & ~7;
+      double sum = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sum += sl + 8 * u < g.nblk ? pyz_gs_join(lo[u], hi[u]) : 0.0;   // (first half's blocks; used by half 0)
+      const double first = __shfl(sum, lane & ~8, 64);   // the first half's sum of this slice
+      if (half) {
+        sum = first;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += sl + 8 * (16 + u) < g.nblk ? pyz_gs_join(lo[u], hi[u]) : 0.0;
+      }
+      const int l0 = (lane & ~15) + 8;   // the lanes that hold the slices' whole sums
       const double s0 = __shfl(sum, l0, 64), s1 = __shfl(sum, l0 + 1, 64), s2 = __shfl(sum, l0 + 2, 64), s3 = __shfl(sum, l0 + 3, 64);
       const double s4 = __shfl(sum, l0 + 4, 64), s5 = __shfl(sum, l0 + 5, 64), s6 = __shfl(sum, l0 + 6, 64), s7 = __shfl(sum, l0 + 7, 64);
-      if (sl == 0 && j < M) {
+      if ((lane & 15) == 0 && j < M) {
         const double dsq = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
         pyz_gs_store_f64(g.kgran + ((long long)(inext & 1) * 64 + j) * 2, tagn, exp(-(double)g.gamma * dsq));
       }
